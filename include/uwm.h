@@ -1,0 +1,141 @@
+/* libuwm — C ABI of the MI355X-native U-Net watermark-segmentation hot path.
+ *
+ * This is the drop-in boundary for ONE path of Dave-he/unet-watermark: the forward / backward of
+ * smp.Unet(resnet18|resnet34) and its Dice + BCE loss, which the reference reaches through
+ *   model = smp.Unet(**kwargs)                /root/reference/src/models/unet_model.py:64-71,93-120
+ *   outputs = model(images)                    /root/reference/src/train.py:91,100,142 ; src/predict.py:339,611
+ *   loss = criterion(outputs, masks)           /root/reference/src/train.py:94,103 ; src/utils/losses.py:11-52
+ *   loss.backward(); optimizer.step()          /root/reference/src/train.py:96-98,104-105
+ *   metrics(sigmoid(outputs), masks)           /root/reference/src/train.py:110-117 ; src/utils/metrics.py:11-37
+ *   (mask > THRESHOLD) * 255                   /root/reference/src/predict.py:614-625
+ * The reference is pure Python and has no FFI of its own; INTEGRATION.md shows the ctypes stub a
+ * maintainer adds (unet-watermark_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every device buffer is CALLER-OWNED (e.g. a torch tensor's
+ *     data_ptr()); the library never allocates or frees device memory, never synchronises the
+ *     host and enqueues all work on the caller's stream (a hipStream_t passed as void*).
+ *   - every function returns 0 on success, non-zero on failure; uwm_last_error() then returns a
+ *     thread-local message.  A handle is bound to one device and is not re-entrant.
+ *   - activations are NHWC fp32 with channels padded to a multiple of 4; logits are returned as
+ *     [N][H][W][CP], CP = uwm_logits_channels() (class k at channel k).
+ *   - parameters live in ONE flat fp32 arena (caller-owned) whose layout the library defines:
+ *     uwm_tensor_info() gives, per smp-compatible state_dict key, the arena offset plus logical
+ *     OIHW shape and element strides (convolution weights are stored [O][kh][kw][I] with each
+ *     output-channel row padded to a multiple of 32 floats).  Gradients use the same layout in a
+ *     second arena; BatchNorm running statistics live in a third ("buffer") arena.
+ */
+#ifndef UWM_H
+#define UWM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uwm_model* uwm_handle;
+typedef void* uwm_stream;              /* hipStream_t */
+
+enum { UWM_ENC_RESNET18 = 18, UWM_ENC_RESNET34 = 34 };
+enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* target dtypes */
+enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
+       UWM_KIND_BN_MEAN = 4, UWM_KIND_BN_VAR = 5 };
+enum { UWM_ARENA_PARAM = 0, UWM_ARENA_BUFFER = 1 };
+
+/* mirrors smp.Unet(encoder_name, encoder_depth=5, decoder_channels, in_channels, classes) */
+typedef struct {
+  int encoder;                 /* UWM_ENC_RESNET18 | UWM_ENC_RESNET34 */
+  int in_channels;             /* 1..4 */
+  int classes;                 /* >= 1 */
+  int decoder_channels[5];     /* e.g. 256,128,64,32,16 ; each a multiple of 4 */
+  float bn_eps;                /* 1e-5 */
+  float bn_momentum;           /* 0.1 */
+} uwm_unet_desc;
+
+typedef struct {
+  char name[96];               /* smp state_dict key, e.g. "encoder.layer1.0.conv1.weight" */
+  int kind;                    /* UWM_KIND_* */
+  int arena;                   /* UWM_ARENA_PARAM | UWM_ARENA_BUFFER */
+  int ndim;                    /* 4 for conv weights, 1 otherwise */
+  long long offset;            /* element offset into the arena */
+  long long shape[4];          /* logical shape (OIHW for conv weights) */
+  long long stride[4];         /* element strides of that logical view */
+} uwm_tensor_info;
+
+const char* uwm_last_error(void);
+int uwm_version(void);
+
+int  uwm_create(const uwm_unet_desc* desc, uwm_handle* out);
+void uwm_destroy(uwm_handle h);
+
+long long uwm_param_arena_floats(uwm_handle h);     /* incl. padding; padding must stay 0 */
+long long uwm_buffer_arena_floats(uwm_handle h);
+long long uwm_param_count(uwm_handle h);            /* logical number of trainable scalars */
+int  uwm_num_tensors(uwm_handle h);
+int  uwm_tensor_info_get(uwm_handle h, int index, uwm_tensor_info* out);
+int  uwm_logits_channels(uwm_handle h);
+
+/* number of backward stages (gradient buckets) and the arena range [begin,end) each one
+ * completes; stage 0 = head+decoder, then encoder layer4, layer3, layer2, layer1+stem. */
+int  uwm_num_stages(uwm_handle h);
+int  uwm_stage_range(uwm_handle h, int stage, long long* begin, long long* end);
+
+/* Bind caller-owned device arenas.  grads may be NULL for inference-only use. */
+int  uwm_bind(uwm_handle h, float* params, float* grads, float* buffers);
+
+size_t uwm_workspace_bytes(uwm_handle h, int N, int H, int W, int training);
+
+/* logits[N][H][W][CP] = Unet(x[N][Cin][H][W]).  training!=0: BatchNorm uses batch statistics,
+ * updates running stats, and the workspace keeps what uwm_backward needs.  H, W % 32 == 0. */
+int  uwm_forward(uwm_handle h, const float* x_nchw, float* logits, void* workspace, size_t workspace_bytes,
+                 int N, int H, int W, int training, uwm_stream stream);
+
+/* Backward of the last training forward held in `workspace`; writes (overwrites) the gradient arena
+ * ranges of stages [stage_begin, stage_end).  Call with (0, uwm_num_stages) for everything, or stage
+ * by stage to overlap gradient all-reduce with the rest of the backward. */
+int  uwm_backward(uwm_handle h, const float* dlogits, void* workspace, int stage_begin, int stage_end,
+                  uwm_stream stream);
+
+/* loss = w_dice*Dice(logits,target) + w_bce*BCEWithLogits(logits,target) over class channel 0.
+ * logits [npix][ld]; target [npix] of dtype target_dtype; scratch: >= 64 bytes device memory;
+ * loss_out: 3 device floats {total, dice, bce}; dlogits [npix][ldd] (may be NULL) = grad_scale*dL/dlogits. */
+int  uwm_loss(const float* logits, int ld, const void* target, int target_dtype, long long npix,
+              float w_dice, float w_bce, float smooth, float eps, void* scratch, float* loss_out,
+              float* dlogits, int ldd, float grad_scale, uwm_stream stream);
+
+/* out[N][4] int64 = tp, fp, fn, tn of (v >= threshold), v = sigmoid(logit) if apply_sigmoid else logit */
+int  uwm_stats(const float* logits, int ld, const void* target, int target_dtype, int N, long long hw,
+               float threshold, int apply_sigmoid, long long* out, uwm_stream stream);
+/* mask[npix] uint8 = (v > threshold) ? 255 : 0 */
+int  uwm_threshold(const float* logits, int ld, long long npix, float threshold, int apply_sigmoid,
+                   uint8_t* mask, uwm_stream stream);
+
+/* torch.optim.Adam (coupled weight decay) over a flat range; step = 1-based step count */
+int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, long long step, float grad_scale, uwm_stream stream);
+int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
+
+/* ---- single-operator entry points (used by the parity tests) ---- */
+typedef struct {
+  const float* ptr; const float* scale; const float* shift;   /* NHWC fp32, optional lazy affine */
+  int C, H, W, up, relu;
+} uwm_src;
+/* y[N][Ho][Wo][Cout] = conv(cat(s0,s1), w) ; w [Cout][Kpad] packed (k = tap*Ctot + c).
+ * stats (2*Cout doubles: sum, sumsq; pre-zeroed) may be NULL. */
+int  uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
+                 int pad, int N, int Cout, const float* bias, float* y, double* stats, int cfg, uwm_stream stream);
+/* dx[N][H][W][Cin] = conv_transpose(dy[N][Ho][Wo][Cout], wd) (+addend, *relu-mask) ; wd [Cin][KpadD] */
+int  uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* wd, int Cin, int KpadD, int kh, int kw,
+                  int stride, int pad, int H, int W, const float* addend, const float* mask, const float* mscale,
+                  const float* mshift, float* dx, uwm_stream stream);
+int  uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, int Ho, int Wo, int Cout, int wrows,
+                  int Kpad, int kh, int kw, int stride, int pad, float* dw, uwm_stream stream);
+int  uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,
+                       uwm_stream stream);
+int  uwm_op_maxpool(const uwm_src* in, int N, float* out, uint8_t* idx, uwm_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UWM_H */

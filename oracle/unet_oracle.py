@@ -1,0 +1,318 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+Plain-torch (CPU, fp32, torch.nn / torch.nn.functional) restatement of the hot
+path that the reference delegates to the third-party package
+`segmentation-models-pytorch` (pinned only as `>=0.3.0`,
+/root/reference/requirements.txt:17):
+
+  * smp.Unet(resnet18|resnet34) forward  <- src/models/unet_model.py:64-71,93-120
+  * smp.losses.DiceLoss(mode='binary')   <- src/utils/losses.py:18-19
+  * nn.BCEWithLogitsLoss / CombinedLoss  <- src/utils/losses.py:22-23,33-52
+  * smp.metrics.get_stats + micro scores <- src/utils/metrics.py:11-37
+  * the train step order                 <- src/train.py:82-107
+  * the predict-time logit threshold     <- src/predict.py:610-625
+
+PARITY UNPINNED at the smp boundary: the smp source is not in /root/reference
+and not installed in this image, and the reference has no test / golden vector
+for this path.  The graph below follows the published smp
+algorithm; every primitive (conv2d, batch_norm, relu,
+max_pool2d, nearest interpolate, cat, logsigmoid, autograd, Adam) is stock
+torch CPU fp32, which is the numerical ground truth.  Self-checks that stand in
+for missing upstream tests live in tests/test_oracle.py (parameter counts,
+state_dict key set, Dice closed forms, all-negative batch => 0).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# resnet block counts: torchvision.models.resnet{18,34} (BasicBlock)
+_RESNET_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+_RESNET_WIDTHS = (64, 128, 256, 512)
+
+
+class BasicBlock(nn.Module):
+    """torchvision BasicBlock: conv3x3-bn-relu-conv3x3-bn (+downsample) -add-relu."""
+
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride, 0, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idn = x if self.downsample is None else self.downsample(x)
+        o = self.relu(self.bn1(self.conv1(x)))
+        o = self.bn2(self.conv2(o))
+        return self.relu(o + idn)
+
+
+class ResNetEncoder(nn.Module):
+    """smp ResNetEncoder (fc/avgpool deleted); features at strides 1,2,4,8,16,32."""
+
+    def __init__(self, name: str, in_channels: int = 3):
+        super().__init__()
+        blocks = _RESNET_BLOCKS[name]
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=False)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for li, (w, nb) in enumerate(zip(_RESNET_WIDTHS, blocks), start=1):
+            layer = []
+            for b in range(nb):
+                layer.append(BasicBlock(cin, w, 2 if (b == 0 and li > 1) else 1))
+                cin = w
+            setattr(self, f"layer{li}", nn.Sequential(*layer))
+        self.out_channels = (in_channels, 64, 64, 128, 256, 512)
+        # torchvision ResNet init (encoder_weights=None)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        f0 = x
+        f1 = self.relu(self.bn1(self.conv1(x)))
+        f2 = self.layer1(self.maxpool(f1))
+        f3 = self.layer2(f2)
+        f4 = self.layer3(f3)
+        f5 = self.layer4(f4)
+        return [f0, f1, f2, f3, f4, f5]
+
+
+def _conv2d_relu(cin, cout):
+    # smp.base.modules.Conv2dReLU(use_batchnorm=True): Sequential(conv(no bias), bn, relu)
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=False))
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, cin, cskip, cout):
+        super().__init__()
+        self.conv1 = _conv2d_relu(cin + cskip, cout)
+        self.conv2 = _conv2d_relu(cout, cout)
+
+    def forward(self, x, skip=None):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        if skip is not None:
+            x = torch.cat([x, skip], dim=1)  # upsampled FIRST, skip SECOND
+        return self.conv2(self.conv1(x))
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]          # (512,256,128,64,64)
+        in_ch = [enc[0]] + list(decoder_channels[:-1])
+        skip_ch = enc[1:] + [0]
+        self.blocks = nn.ModuleList(
+            [DecoderBlock(i, s, o) for i, s, o in zip(in_ch, skip_ch, decoder_channels)])
+        for m in self.modules():                         # smp initialize_decoder
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, *features):
+        feats = features[1:][::-1]
+        x, skips = feats[0], feats[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class OracleUnet(nn.Module):
+    """smp.Unet(encoder_name, encoder_depth=5, encoder_weights=None, decoder_channels,
+    in_channels, classes, activation=None) — SURVEY.md Appendix A.1-A.4."""
+
+    def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None,
+                 decoder_use_batchnorm=True, decoder_channels=(256, 128, 64, 32, 16),
+                 decoder_attention_type=None, in_channels=3, classes=1, activation=None,
+                 aux_params=None):
+        super().__init__()
+        if encoder_name not in _RESNET_BLOCKS:
+            raise ValueError(f"oracle supports {list(_RESNET_BLOCKS)}; got {encoder_name}")
+        if encoder_depth != 5 or len(decoder_channels) != encoder_depth:
+            raise ValueError("decoder_channels length must equal encoder_depth (=5)")
+        if encoder_weights is not None or decoder_attention_type is not None \
+                or activation is not None or aux_params is not None or not decoder_use_batchnorm:
+            raise ValueError("oracle: unsupported option")
+        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        self.decoder = UnetDecoder(self.encoder.out_channels, tuple(decoder_channels))
+        head = nn.Conv2d(decoder_channels[-1], classes, 3, 1, 1)
+        nn.init.xavier_uniform_(head.weight)             # smp initialize_head
+        nn.init.constant_(head.bias, 0)
+        self.segmentation_head = nn.Sequential(head, nn.Identity(), nn.Identity())
+
+    def forward(self, x):
+        h, w = x.shape[-2:]
+        if h % 32 != 0 or w % 32 != 0:
+            raise RuntimeError(
+                f"Wrong input shape height={h}, width={w}. Expected image height and width "
+                f"divisible by 32.")
+        return self.segmentation_head(self.decoder(*self.encoder(x)))
+
+
+# ----------------------------------------------------------------------------- losses
+class DiceLoss(nn.Module):
+    """smp.losses.DiceLoss(mode='binary', from_logits=True, log_loss=False, eps=1e-7)
+    (reference call site src/utils/losses.py:18-19, smooth=cfg.LOSS.SMOOTH)."""
+
+    def __init__(self, mode="binary", smooth=0.0, eps=1e-7):
+        super().__init__()
+        assert mode == "binary"
+        self.smooth, self.eps = float(smooth), float(eps)
+
+    def forward(self, y_pred, y_true):
+        bs = y_true.size(0)
+        p = F.logsigmoid(y_pred).exp()
+        t = y_true.view(bs, 1, -1).type_as(p)
+        p = p.view(bs, 1, -1)
+        inter = torch.sum(p * t, dim=(0, 2))
+        card = torch.sum(p + t, dim=(0, 2))
+        score = (2.0 * inter + self.smooth) / (card + self.smooth).clamp_min(self.eps)
+        loss = (1.0 - score) * (t.sum((0, 2)) > 0).to(score.dtype)
+        return loss.mean()
+
+
+class BCEWithLogits(nn.Module):
+    """nn.BCEWithLogitsLoss() with the float cast the int64 masks need."""
+
+    def forward(self, y_pred, y_true):
+        return F.binary_cross_entropy_with_logits(y_pred, y_true.type_as(y_pred))
+
+
+class CombinedLoss(nn.Module):
+    """src/utils/losses.py:33-52 — sum_i w_i * loss_i."""
+
+    def __init__(self, losses, weights=None):
+        super().__init__()
+        self.losses = list(losses)
+        self.weights = list(weights) if weights else [1.0] * len(self.losses)
+
+    def forward(self, pred, target):
+        total = 0
+        for fn, w in zip(self.losses, self.weights):
+            total = total + w * fn(pred, target)
+        return total
+
+
+# ---------------------------------------------------------------------------- metrics
+def get_stats(output: torch.Tensor, target: torch.Tensor, threshold=0.5):
+    """smp.metrics.get_stats(mode='binary', threshold) -> tp, fp, fn, tn int64 (N,1)."""
+    n = output.shape[0]
+    o = (output >= threshold).reshape(n, 1, -1).to(torch.int64)
+    t = target.reshape(n, 1, -1).to(torch.int64)
+    tp = (o * t).sum(2)
+    fp = o.sum(2) - tp
+    fn = t.sum(2) - tp
+    tn = o.shape[2] - tp - fp - fn
+    return tp, fp, fn, tn
+
+
+def _div(a, b):
+    a, b = float(a), float(b)
+    return 1.0 if b == 0 else a / b           # zero_division=1.0
+
+
+def micro_metrics(tp, fp, fn, tn):
+    """src/utils/metrics.py:22-35 with reduction='micro'."""
+    tp, fp, fn, tn = (int(v.sum()) for v in (tp, fp, fn, tn))
+    return {
+        "iou": _div(tp, tp + fp + fn),
+        "f1": _div(2 * tp, 2 * tp + fp + fn),
+        "accuracy": _div(tp + tn, tp + fp + fn + tn),
+        "recall": _div(tp, tp + fn),
+        "precision": _div(tp, tp + fp),
+    }
+
+
+def compute_metrics(output, target):
+    return micro_metrics(*get_stats(output, target, 0.5))
+
+
+def predict_mask(logits: torch.Tensor, threshold=0.5, apply_sigmoid=False):
+    """src/predict.py:614-625 thresholds RAW LOGITS (no sigmoid) -> uint8 {0,255}."""
+    v = torch.sigmoid(logits) if apply_sigmoid else logits
+    return ((v > threshold).to(torch.uint8) * 255)
+
+
+# ------------------------------------------------------------------------ synthetic IO
+def synthetic_batch(n: int, h: int, w: int, seed: int = 42, in_channels: int = 3):
+    """BASELINE.md §3 inputs: x = randn(N,C,H,W); int64 masks with one seeded filled
+    rectangle of 5-20 % area per image."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, in_channels, h, w, generator=g)
+    t = torch.zeros(n, h, w, dtype=torch.int64)
+    for i in range(n):
+        frac = 0.05 + 0.15 * float(torch.rand((), generator=g))
+        asp = 0.5 + float(torch.rand((), generator=g))
+        rh = max(1, min(h, int(round((frac * h * w * asp) ** 0.5))))
+        rw = max(1, min(w, int(round(frac * h * w / rh))))
+        y0 = int(torch.randint(0, h - rh + 1, (), generator=g))
+        x0 = int(torch.randint(0, w - rw + 1, (), generator=g))
+        t[i, y0:y0 + rh, x0:x0 + rw] = 1
+    return x, t
+
+
+def build(encoder_name="resnet34", seed=42, **kw) -> OracleUnet:
+    torch.manual_seed(seed)
+    return OracleUnet(encoder_name=encoder_name, **kw)
+
+
+def train_step(model, criterion, optimizer, images, masks):
+    """CPU branch of src/train.py:86,100-105: zero_grad, fwd, unsqueeze, loss, bwd, step."""
+    optimizer.zero_grad()
+    outputs = model(images)
+    if masks.dim() == 3:
+        masks = masks.unsqueeze(1)
+    loss = criterion(outputs, masks)
+    loss.backward()
+    optimizer.step()
+    return outputs.detach(), loss.detach()
+
+
+def conv_flops(encoder_name="resnet34", h=512, w=512, decoder_channels=(256, 128, 64, 32, 16),
+               in_channels=3, classes=1):
+    """Algorithmic conv FLOPs per image: (fwd, fwd+bwd) — SURVEY.md §8(d)."""
+    macs = []          # (macs, needs_dgrad)
+    def conv(cin, cout, k, ho, wo, dgrad=True):
+        macs.append((cin * cout * k * k * ho * wo, dgrad))
+    conv(in_channels, 64, 7, h // 2, w // 2, dgrad=False)
+    cin, hh, ww = 64, h // 4, w // 4
+    for li, (wd, nb) in enumerate(zip(_RESNET_WIDTHS, _RESNET_BLOCKS[encoder_name]), start=1):
+        for b in range(nb):
+            s = 2 if (b == 0 and li > 1) else 1
+            hh, ww = hh // s, ww // s
+            conv(cin, wd, 3, hh, ww)
+            conv(wd, wd, 3, hh, ww)
+            if s != 1 or cin != wd:
+                conv(cin, wd, 1, hh, ww)
+            cin = wd
+    enc = [512, 256, 128, 64, 64]
+    in_ch = [enc[0]] + list(decoder_channels[:-1])
+    skip = enc[1:] + [0]
+    for i, s, o in zip(in_ch, skip, decoder_channels):
+        hh, ww = hh * 2, ww * 2
+        conv(i + s, o, 3, hh, ww)
+        conv(o, o, 3, hh, ww)
+    conv(decoder_channels[-1], classes, 3, hh, ww)
+    fwd = 2 * sum(m for m, _ in macs)
+    bwd = 2 * sum(m * (2 if d else 1) for m, d in macs)
+    return fwd, fwd + bwd

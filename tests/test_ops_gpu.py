@@ -1,0 +1,204 @@
+"""GPU parity of libuwm's single-operator entry points against torch CPU fp32 primitives
+(the oracle's primitives — SURVEY.md §8c).  Tolerances: fp32 accumulation-order noise only
+(exact-fp32 MFMA), stated per test."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import nhwc, nchw, pack_w, unpack_w, src, P, stream, rup
+
+pytestmark = pytest.mark.gpu
+
+
+def lib():
+    from unet_watermark_amd import _lib as L
+    return L
+
+
+def _conv_case(dev, n, cin, cout, h, w, k, stride, pad, cfg=-1, lazy=False, seed=0):
+    L = lib()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)
+    xin = x
+    scale = shift = None
+    if lazy:
+        scale = torch.rand(rup(cin, 4), generator=g) + 0.5
+        scale[::3] *= -1
+        shift = torch.randn(rup(cin, 4), generator=g) * 0.3
+        xin = torch.relu(x * scale[:cin, None, None] + shift[:cin, None, None])
+    ref = F.conv2d(xin, wt, None, stride, pad)
+    xd = nhwc(x).to(dev)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(dev)
+    coutp = rup(cout, 4)
+    ho, wo = ref.shape[-2:]
+    y = torch.full((n, ho, wo, coutp), float("nan"), device=dev)
+    stats = torch.zeros(2 * coutp, dtype=torch.float64, device=dev)
+    sc = scale.to(dev) if lazy else None
+    sh = shift.to(dev) if lazy else None
+    s0 = src(xd, sc, sh, relu=1 if lazy else 0)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), cout, kpad, k, k, stride, pad, n, coutp, None, P(y), P(stats),
+                                cfg, stream()))
+    torch.cuda.synchronize()
+    got = nchw(y.cpu(), cout)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.isfinite(y).all()
+    assert (got - ref).abs().max() < tol, f"conv max err {(got - ref).abs().max()}"
+    if coutp > cout:
+        assert (y[..., cout:] == 0).all()
+    # BatchNorm statistics of the output
+    ssum = stats[:cout].cpu()
+    ssq = stats[coutp:coutp + cout].cpu()
+    rs = ref.double().sum((0, 2, 3))
+    rq = (ref.double() ** 2).sum((0, 2, 3))
+    assert torch.allclose(ssum, rs, rtol=1e-5, atol=1e-3 * max(1.0, float(rs.abs().max())) * 1e-2)
+    assert torch.allclose(ssq, rq, rtol=1e-5, atol=1e-5 * float(rq.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_conv3x3_all_tile_configs(cuda, cfg):
+    # layer1.0.conv1-like (reduced): every tile configuration must give the same answer,
+    # including tiles that over-hang M and Cout.
+    _conv_case(cuda, 2, 64, 64, 24, 40, 3, 1, 1, cfg=cfg)
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 3, 64, 64, 64, 7, 2, 3),      # stem: Cin 3->4 pad, 7x7 s2, K=196->224
+    (2, 64, 128, 32, 32, 3, 2, 1),    # layer2.0.conv1: stride 2
+    (2, 64, 128, 32, 32, 1, 2, 0),    # downsample 1x1 s2
+    (1, 16, 16, 32, 64, 3, 1, 1),     # decoder block 4 conv2: Cin=16 (two taps per 32-chunk)
+    (1, 16, 1, 32, 32, 3, 1, 1),      # head: Cout 1 -> padded 4
+    (3, 256, 512, 8, 8, 3, 1, 1),     # deep stage, ragged M (192 pixels)
+    (1, 128, 32, 16, 48, 3, 1, 1),    # Cout 32 tile
+])
+def test_conv_shapes(cuda, shape):
+    n, cin, cout, h, w, k, s, p = shape
+    _conv_case(cuda, n, cin, cout, h, w, k, s, p)
+
+
+def test_conv_lazy_bn_relu_prologue(cuda):
+    # consumer-side BatchNorm-apply + ReLU (negative scales included) and zero padding AFTER it
+    _conv_case(cuda, 2, 64, 64, 16, 16, 3, 1, 1, lazy=True)
+    _conv_case(cuda, 2, 16, 32, 16, 16, 3, 1, 1, lazy=True, seed=3)
+
+
+def test_conv_upsample_concat(cuda):
+    """decoder block conv1: cat(nearest_x2(d), skip) fused into the gather; both sources lazy."""
+    L = lib()
+    g = torch.Generator().manual_seed(1)
+    n, c0, c1, cout, h, w = 2, 64, 32, 32, 8, 12
+    d = torch.randn(n, c0, h, w, generator=g)
+    sk = torch.randn(n, c1, 2 * h, 2 * w, generator=g)
+    sc0, sh0 = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    sc1, sh1 = torch.rand(c1, generator=g) + 0.5, torch.randn(c1, generator=g) * 0.2
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
+    a0 = torch.relu(d * sc0[:, None, None] + sh0[:, None, None])
+    a1 = torch.relu(sk * sc1[:, None, None] + sh1[:, None, None])
+    ref = F.conv2d(torch.cat([F.interpolate(a0, scale_factor=2, mode="nearest"), a1], 1), wt, None, 1, 1)
+    dd, skd = nhwc(d).to(cuda), nhwc(sk).to(cuda)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(cuda)
+    t = [sc0.to(cuda), sh0.to(cuda), sc1.to(cuda), sh1.to(cuda)]
+    y = torch.empty(n, 2 * h, 2 * w, cout, device=cuda)
+    s0, s1 = src(dd, t[0], t[1], relu=1, up=1), src(skd, t[2], t[3], relu=1)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), C.byref(s1), P(wp), cout, kpad, 3, 3, 1, 1, n, cout, None, P(y), None, -1,
+                                stream()))
+    torch.cuda.synchronize()
+    assert (nchw(y.cpu()) - ref).abs().max() < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 16, 24, 3, 1, 1),
+    (2, 64, 128, 32, 32, 3, 2, 1),
+    (2, 64, 128, 32, 32, 1, 2, 0),
+    (1, 16, 1, 32, 32, 3, 1, 1),      # head dgrad: dy has 1 -> 4 padded channels
+    (1, 96, 32, 16, 16, 3, 1, 1),     # concat input (Ctot=96): dgrad output is the full dcat
+])
+def test_dgrad_and_wgrad(cuda, shape):
+    L = lib()
+    n, cin, cout, h, w, k, s, p = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(x, wt, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ho, wo = y.shape[-2:]
+    coutp = rup(cout, 4)
+    wp, kpad = pack_w(wt.detach())
+    wp = wp.to(cuda)
+    kpadd = rup(k * k * coutp, 32)
+    wd = torch.empty(cin, kpadd, device=cuda)
+    L.check(L.lib().uwm_op_pack_dgrad(P(wp), cout, kpad, k * k, cin, P(wd), kpadd, coutp, stream()))
+    dyd = nhwc(dy).to(cuda)
+    addend = torch.randn(n, h, w, cin, generator=g)
+    maskt = torch.randn(n, h, w, cin, generator=g)
+    add_d, mask_d = addend.to(cuda), maskt.to(cuda)
+    dx = torch.empty(n, h, w, cin, device=cuda)
+    L.check(L.lib().uwm_op_dgrad(P(dyd), n, ho, wo, coutp, P(wd), cin, kpadd, k, k, s, p, h, w, P(add_d), P(mask_d), None,
+                                 None, P(dx), stream()))
+    dw = torch.zeros(cout, kpad, device=cuda)
+    xd = nhwc(x.detach()).to(cuda)
+    s0 = src(xd)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, ho, wo, coutp, cout, kpad, k, k, s, p, P(dw), stream()))
+    torch.cuda.synchronize()
+    ref_dx = (x.grad.permute(0, 2, 3, 1) + addend) * (maskt > 0)
+    assert (dx.cpu() - ref_dx).abs().max() < 3e-5 * max(1.0, float(ref_dx.abs().max()))
+    got_dw = unpack_w(dw.cpu(), cout, cin, k, k)
+    assert (got_dw - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+    # padded K region of dW must stay exactly zero (it aliases arena padding)
+    assert (dw[:, k * k * rup(cin, 4):] == 0).all()
+
+
+def test_wgrad_lazy_upsample_concat(cuda):
+    L = lib()
+    g = torch.Generator().manual_seed(7)
+    n, c0, c1, cout, h, w = 2, 32, 16, 16, 8, 8
+    d = torch.randn(n, c0, h, w, generator=g)
+    sk = torch.randn(n, c1, 2 * h, 2 * w, generator=g)
+    sc0, sh0 = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    a0 = torch.relu(d * sc0[:, None, None] + sh0[:, None, None])
+    xin = torch.cat([F.interpolate(a0, scale_factor=2, mode="nearest"), sk], 1)
+    wt = (torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(xin, wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dd, skd, dyd = nhwc(d).to(cuda), nhwc(sk).to(cuda), nhwc(dy).to(cuda)
+    t = [sc0.to(cuda), sh0.to(cuda)]
+    kpad = rup(9 * (c0 + c1), 32)
+    dw = torch.zeros(cout, kpad, device=cuda)
+    s0, s1 = src(dd, t[0], t[1], relu=1, up=1), src(skd)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), C.byref(s1), P(dyd), n, 2 * h, 2 * w, cout, cout, kpad, 3, 3, 1, 1, P(dw),
+                                 stream()))
+    torch.cuda.synchronize()
+    got = unpack_w(dw.cpu(), cout, c0 + c1, 3, 3)
+    assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+
+
+def test_maxpool_ties_and_lazy_input(cuda):
+    """3x3 s2 p1 max-pool over relu(bn(y)): post-ReLU zeros tie; the FIRST max in scan order wins,
+    as torch's CPU kernel does, so the argmax (and with it the backward) matches."""
+    L = lib()
+    g = torch.Generator().manual_seed(2)
+    n, c, h, w = 2, 64, 16, 24
+    y = torch.randn(n, c, h, w, generator=g)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.5 - 0.5
+    a = torch.relu(y * sc[:, None, None] + sh[:, None, None])
+    ref, ridx = F.max_pool2d(a, 3, 2, 1, return_indices=True)
+    yd = nhwc(y).to(cuda)
+    t = [sc.to(cuda), sh.to(cuda)]
+    out = torch.empty(n, h // 2, w // 2, c, device=cuda)
+    idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=cuda)
+    s0 = src(yd, t[0], t[1], relu=1)
+    L.check(L.lib().uwm_op_maxpool(C.byref(s0), n, P(out), P(idx), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(out.cpu()), ref)
+    # decode our tap index to torch's flat input index
+    tap = nchw(idx.cpu()).long()
+    ho = torch.arange(h // 2).view(1, 1, -1, 1)
+    wo = torch.arange(w // 2).view(1, 1, 1, -1)
+    flat = (ho * 2 - 1 + tap // 3) * w + (wo * 2 - 1 + tap % 3)
+    assert torch.equal(flat, ridx)

@@ -1,0 +1,147 @@
+"""ctypes binding of libuwm.so (include/uwm.h) — the stub INTEGRATION.md describes.
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every entry
+point raises.  Nothing here imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+_PKG_DIR = Path(__file__).resolve().parent
+_CSRC = _PKG_DIR / "csrc"
+LIB_PATH = _PKG_DIR / "libuwm.so"
+SOURCES = ["conv_igemm.hip", "wgrad_igemm.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+HIP_ARCH = "gfx950"
+
+
+class uwm_unet_desc(C.Structure):
+    _fields_ = [("encoder", C.c_int), ("in_channels", C.c_int), ("classes", C.c_int),
+                ("decoder_channels", C.c_int * 5), ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+
+
+class uwm_tensor_info(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("kind", C.c_int), ("arena", C.c_int), ("ndim", C.c_int),
+                ("offset", C.c_longlong), ("shape", C.c_longlong * 4), ("stride", C.c_longlong * 4)]
+
+
+class uwm_src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("up", C.c_int), ("relu", C.c_int)]
+
+
+KIND_CONV_W, KIND_BIAS, KIND_BN_GAMMA, KIND_BN_BETA, KIND_BN_MEAN, KIND_BN_VAR = range(6)
+ARENA_PARAM, ARENA_BUFFER = 0, 1
+ENC = {"resnet18": 18, "resnet34": 34}
+P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# every symbol include/uwm.h declares: (restype, argtypes)
+SIGNATURES = {
+    "uwm_last_error": (C.c_char_p, []),
+    "uwm_version": (I, []),
+    "uwm_create": (I, [C.POINTER(uwm_unet_desc), C.POINTER(P)]),
+    "uwm_destroy": (None, [P]),
+    "uwm_param_arena_floats": (L, [P]),
+    "uwm_buffer_arena_floats": (L, [P]),
+    "uwm_param_count": (L, [P]),
+    "uwm_num_tensors": (I, [P]),
+    "uwm_tensor_info_get": (I, [P, I, C.POINTER(uwm_tensor_info)]),
+    "uwm_logits_channels": (I, [P]),
+    "uwm_num_stages": (I, [P]),
+    "uwm_stage_range": (I, [P, I, C.POINTER(L), C.POINTER(L)]),
+    "uwm_bind": (I, [P, P, P, P]),
+    "uwm_workspace_bytes": (Z, [P, I, I, I, I]),
+    "uwm_forward": (I, [P, P, P, P, Z, I, I, I, I, P]),
+    "uwm_backward": (I, [P, P, P, I, I, P]),
+    "uwm_loss": (I, [P, I, P, I, L, F, F, F, F, P, P, P, I, F, P]),
+    "uwm_stats": (I, [P, I, P, I, I, L, F, I, P, P]),
+    "uwm_threshold": (I, [P, I, L, F, I, P, P]),
+    "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
+    "uwm_scale": (I, [P, L, F, P]),
+    "uwm_op_conv": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, P, P, P, I, P]),
+    "uwm_op_dgrad": (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P]),
+    "uwm_op_wgrad": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, I, I, P, P]),
+    "uwm_op_pack_dgrad": (I, [P, I, I, I, I, P, I, I, P]),
+    "uwm_op_maxpool": (I, [C.POINTER(uwm_src), I, P, P, P]),
+}
+
+_lib = None
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 into libuwm.so (hipcc cross-compiles without a GPU)."""
+    srcs = [_CSRC / s for s in SOURCES]
+    hdrs = [_CSRC / "uwm_kernels.h", _PKG_DIR.parent / "include" / "uwm.h"]
+    if LIB_PATH.exists() and not force:
+        newest = max(p.stat().st_mtime for p in srcs + hdrs)
+        if LIB_PATH.stat().st_mtime >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = _PKG_DIR / "build"
+    objdir.mkdir(exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = objdir / (s.stem + ".o")
+        cmd = [hipcc, f"--offload-arch={HIP_ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o)]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), o))
+    objs = []
+    for cmd, p, o in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{out.decode(errors='replace')}")
+        if verbose and out:
+            sys.stderr.write(out.decode(errors="replace"))
+        objs.append(str(o))
+    cmd = [hipcc, f"--offload-arch={HIP_ARCH}", "-shared", "-fPIC", "-o", str(LIB_PATH)] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout.decode(errors='replace')}")
+    return LIB_PATH
+
+
+def lib():
+    """Load libuwm.so (raises RuntimeError when the HIP extension is not built / not loadable)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (needs hipcc). There is no CPU fallback for this path.")
+    try:
+        h = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # missing libamdhip64 etc.
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)       # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return _lib
+
+
+def check(rc: int, exc=RuntimeError):
+    if rc != 0:
+        msg = lib().uwm_last_error().decode(errors="replace")
+        raise exc(msg)
+
+
+def stream_ptr(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_DT = None
+
+
+def target_dtype_code(t) -> int:
+    import torch
+    global _DT
+    if _DT is None:
+        _DT = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.int32: 3, torch.bool: 2}
+    if t.dtype not in _DT:
+        raise TypeError(f"unsupported target dtype {t.dtype}")
+    return _DT[t.dtype]

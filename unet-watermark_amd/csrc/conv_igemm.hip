@@ -1,0 +1,278 @@
+// Implicit-GEMM convolution for gfx950 (MI355X) on the exact-fp32 matrix core
+// instruction v_mfma_f32_16x16x4_f32.
+//
+//   D[co][pixel] += sum_k W[co][k] * X[pixel][k],   k = tap*Ctot + c
+//
+// * A operand = weights (rows = output channels), B operand = gathered input pixels, so each
+//   lane ends up holding 4 CONSECUTIVE output channels of one pixel -> one 16-byte NHWC store.
+// * X is gathered on the fly (no im2col buffer): per 16-byte unit the loader derives
+//   (tap, channel, source) and applies the producer's BatchNorm scale/shift + ReLU, nearest x2
+//   upsampling and channel concat while staging the tile (register-staged, double-buffered LDS).
+// * LDS tile rows are 32 floats (128 B) with the 16-byte unit index XOR-swizzled by (row>>1)&7:
+//   conflict-free for the ds_read_b128 lane groups of gfx950.
+// * The same kernel runs dgrad: transposed gather (rmul=-1, sdiv=stride) over a [Cin][tap][Cout]
+//   repack of the weights; its epilogue can add a residual gradient and apply a ReLU mask.
+// * Optional per-channel sum / sum-of-squares of the output (BatchNorm batch statistics) are
+//   reduced in-wave (DPP), across waves through LDS and across blocks with fp64 atomics.
+//
+// Reference semantics replaced: torch.nn.functional.conv2d as used by smp.Unet
+// (/root/reference/src/models/unet_model.py:64-71 -> smp; SURVEY.md §8 a3-a11,a14).
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
+  return f.d <= 1 ? n : __umulhi(n, f.mg);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int MI = BM / WM / 16;      // 16-pixel MFMA tiles per wave
+  constexpr int NI = BN / WN / 16;      // 16-channel MFMA tiles per wave
+  constexpr int XR = BM / 32;           // X rows staged per thread
+  constexpr int WR = (BN + 31) / 32;    // W rows staged per thread
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Xs = smem;                       // [2][BM][32]
+  float* const Ws = smem + 2 * BM * 32;         // [2][BN][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware bijective block remap: blocks that share an XCD (bid % 8) get a contiguous range
+  // of tiles, so halo rows / the weight panel stay in that XCD's L2.
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesN = (a.Cout + BN - 1) / BN;
+  const int tm = tile / tilesN, tn = tile - tm * tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int unit = tid & 7, r0 = tid >> 3;
+
+  // per staged row: pixel -> (n, ho, wo)
+  int rn[XR], rh[XR], rw[XR];
+  unsigned rvalid = 0;
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < XR; ++i) {
+    int m = m0 + r0 + 32 * i;
+    bool v = m < a.M;
+    int mm = v ? m : 0;
+    int n = mm / HoWo, rem = mm - n * HoWo;
+    int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    rn[i] = n; rh[i] = ho * a.smul + a.off; rw[i] = wo * a.smul + a.off;
+    rvalid |= (v ? 1u : 0u) << i;
+  }
+
+  f4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  f4 xr[XR], wr[WR], tsc, tsh;
+  unsigned xvalid = 0; int trelu = 0; bool thas = false;
+
+  auto load_chunk = [&](int kc) {
+    const unsigned k = kc * 32 + unit * 4;
+    const unsigned tap = fdiv(k, a.dv_ctot);
+    const int c = k - tap * a.Ctot;
+    const unsigned r = fdiv(tap, a.dv_kw);
+    const int s = tap - r * a.kw;
+    const bool tv = tap < (unsigned)a.ntaps;
+    const bool first = c < a.C0;
+    const float* sp = first ? a.s0.ptr : a.s1.ptr;
+    const float* ssc = first ? a.s0.scale : a.s1.scale;
+    const float* ssh = first ? a.s0.shift : a.s1.shift;
+    const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
+    const int sup = first ? a.s0.up : a.s1.up;
+    trelu = first ? a.s0.relu : a.s1.relu;
+    const int cc = first ? c : c - a.C0;
+    thas = (ssc != nullptr) && tv;
+    if (thas) { tsc = *(const f4*)(ssc + cc); tsh = *(const f4*)(ssh + cc); }
+    const int dr = (int)r * a.rmul, ds = s * a.rmul;
+    xvalid = 0;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      int hn = rh[i] + dr, wq = rw[i] + ds;
+      bool v = tv && ((rvalid >> i) & 1u);
+      if (a.sdiv == 2) { v = v && (((hn | wq) & 1) == 0); hn >>= 1; wq >>= 1; }
+      v = v && hn >= 0 && hn < a.Hl && wq >= 0 && wq < a.Wl;
+      hn >>= sup; wq >>= sup;
+      const float* p = sp + ((size_t)((size_t)rn[i] * sH + hn) * sW + wq) * sC + cc;
+      xr[i] = v ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
+      xvalid |= (v ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      int row = n0 + r0 + 32 * i;
+      bool v = (row < a.wrows) && (BN >= 32 || r0 < BN);
+      wr[i] = v ? *(const f4*)(a.w + (size_t)row * a.Kpad + kc * 32 + unit * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* xs = Xs + buf * BM * 32;
+    float* ws = Ws + buf * BN * 32;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      f4 v = xr[i];
+      if (thas) {
+        v = v * tsc + tsh;
+        if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (!((xvalid >> i) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      }
+      const int row = r0 + 32 * i;
+      *(f4*)(xs + row * 32 + ((unit ^ ((row >> 1) & 7)) << 2)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const int row = r0 + 32 * i;
+      if (BN >= 32 || r0 < BN) *(f4*)(ws + row * 32 + ((unit ^ ((row >> 1) & 7)) << 2)) = wr[i];
+    }
+  };
+
+  const int nk = a.Kpad >> 5;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int lrow = lane & 15, lq = lane >> 4;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nk) load_chunk(kc + 1);
+    const float* xs = Xs + cur * BM * 32;
+    const float* ws = Ws + cur * BN * 32;
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16) {
+      f4 xf[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = (wm * MI + i) * 16 + lrow;
+        xf[i] = *(const f4*)(xs + row * 32 + (((k16 * 4 + lq) ^ ((row >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = (wn * NI + j) * 16 + lrow;
+        wf[j] = *(const f4*)(ws + row * 32 + (((k16 * 4 + lq) ^ ((row >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[i][e], acc[i][j], 0, 0, 0);
+    }
+    if (kc + 1 < nk) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: lane (p = lane&15 -> pixel, q = lane>>4 -> 4 channels) --------------
+  const bool do_stats = a.ssum != nullptr;
+  f4 ps[NI], pq[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { ps[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq[j] = ps[j]; }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + (wm * MI + i) * 16 + lrow;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int co = n0 + (wn * NI + j) * 16 + lq * 4;
+      if (m < a.M && co < a.Cout) {
+        f4 v = acc[i][j];
+        const size_t o = (size_t)m * a.Cout + co;
+        if (a.bias) v += *(const f4*)(a.bias + co);
+        if (a.addend) v += *(const f4*)(a.addend + o);
+        if (a.mask) {
+          f4 mk = *(const f4*)(a.mask + o);
+          if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        *(f4*)(a.out + o) = v;
+        ps[j] += v; pq[j] += v * v;
+      }
+    }
+  }
+  if (do_stats) {
+    // reduce over the 16 pixel lanes (xor 1,2,4,8 stays inside a 16-lane row)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = ps[j][e], q = pq[j][e];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+        ps[j][e] = s; pq[j][e] = q;
+      }
+    float* red = smem;                       // [WM][BN][2]; main-loop LDS is dead after the last barrier
+    if (lrow == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cl = (wn * NI + j) * 16 + lq * 4 + e;
+          red[(wm * BN + cl) * 2 + 0] = ps[j][e];
+          red[(wm * BN + cl) * 2 + 1] = pq[j][e];
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = n0 + tid;
+      if (co < a.Cout) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s += (double)red[(w * BN + tid) * 2]; q += (double)red[(w * BN + tid) * 2 + 1]; }
+        atomicAdd(a.ssum + co, s);
+        atomicAdd(a.ssq + co, q);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st) {
+  const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+// tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}
+hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
+  if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
+  int cfg = force_cfg;
+  if (cfg < 0) {
+    const long tiles128 = (long)((a.M + 127) / 128);
+    if (a.Cout <= 16) cfg = 3;
+    else if (a.Cout <= 32) cfg = 2;
+    else if (a.Cout <= 64) cfg = (tiles128 >= 512) ? 1 : 4;
+    else {
+      const long b0 = tiles128 * ((a.Cout + 127) / 128);
+      if (b0 >= 512) cfg = 0;
+      else if (tiles128 * ((a.Cout + 63) / 64) >= 512) cfg = 1;
+      else cfg = 4;
+    }
+  }
+  switch (cfg) {
+    case 0: return launch_cfg<128, 128, 2, 2>(a, st);
+    case 1: return launch_cfg<128, 64, 2, 2>(a, st);
+    case 2: return launch_cfg<128, 32, 4, 1>(a, st);
+    case 3: return launch_cfg<128, 16, 4, 1>(a, st);
+    case 4: return launch_cfg<64, 64, 2, 2>(a, st);
+    case 5: return launch_cfg<64, 128, 1, 4>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace uwm

@@ -1,0 +1,395 @@
+// HBM-bound helper kernels of the U-Net path (gfx950): layout change, BatchNorm finalize /
+// backward, residual add, max-pool, upsample-concat gradient split, weight repack, Adam.
+// All are 16-byte vectorised over the NHWC channel dimension (C % 4 == 0 everywhere).
+// Reference semantics replaced: torch BatchNorm2d / ReLU / MaxPool2d / interpolate+cat autograd
+// and optim.Adam as driven by /root/reference/src/train.py:96-105 (SURVEY.md §8 a4,a9,a10,a14,a15).
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+static constexpr int kMaxBlocks = 256 * 8;
+
+static inline unsigned nblocks(size_t work, int per_block) {
+  size_t b = (work + per_block - 1) / per_block;
+  if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ------------------------------------------------------------------ NCHW -> NHWC(pad 4)
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, size_t HW,
+                                     size_t total, int CP) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, p = i - n * HW;
+    const float* xp = x + n * C * HW + p;
+    float* yp = y + i * CP;
+    for (int c0 = 0; c0 < CP; c0 += 4) {
+      f4 v;
+      v.x = c0 + 0 < C ? xp[(size_t)(c0 + 0) * HW] : 0.f;
+      v.y = c0 + 1 < C ? xp[(size_t)(c0 + 1) * HW] : 0.f;
+      v.z = c0 + 2 < C ? xp[(size_t)(c0 + 2) * HW] : 0.f;
+      v.w = c0 + 3 < C ? xp[(size_t)(c0 + 3) * HW] : 0.f;
+      *(f4*)(yp + c0) = v;
+    }
+  }
+}
+hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st) {
+  const size_t HW = (size_t)H * W, total = (size_t)N * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, x, y, C, HW, total, CP);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BatchNorm finalize
+__global__ void bn_finalize_kernel(const double* ssum, const double* ssq, const float* gamma, const float* beta,
+                                   float* run_mean, float* run_var, float* mean, float* rstd, float* scale,
+                                   float* shift, int C, double count, float eps, float momentum, int upd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = ssum[c] / count;
+  double var = ssq[c] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma[c], b = beta[c];
+  mean[c] = (float)mu; rstd[c] = (float)rs;
+  const float sc = (float)((double)g * rs);
+  scale[c] = sc; shift[c] = (float)((double)b - mu * (double)g * rs);
+  if (upd) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mu);
+    run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unb);
+  }
+}
+hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,
+                              float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
+                              int C, double count, float eps, float momentum, int update_running, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ssum, ssq, gamma, beta, run_mean,
+                     run_var, mean, rstd, scale, shift, C, count, eps, momentum, update_running);
+  return hipGetLastError();
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
+                               float* shift, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double rs = 1.0 / sqrt((double)rv[c] + (double)eps);
+  scale[c] = (float)((double)gamma[c] * rs);
+  shift[c] = (float)((double)beta[c] - (double)rm[c] * (double)gamma[c] * rs);
+}
+hipError_t launch_bn_eval(const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                          float* scale, float* shift, int C, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, st, gamma, beta, run_mean, run_var, scale,
+                     shift, C, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ residual add + ReLU
+__global__ void residual_kernel(const float* __restrict__ y, const float* __restrict__ s2, const float* __restrict__ b2,
+                                const float* __restrict__ id, const float* __restrict__ sd, const float* __restrict__ bd,
+                                float* __restrict__ out, size_t n4, int C) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % (size_t)C);
+    f4 v = *(const f4*)(y + i * 4) * *(const f4*)(s2 + c) + *(const f4*)(b2 + c);
+    f4 r = *(const f4*)(id + i * 4);
+    if (sd) r = r * *(const f4*)(sd + c) + *(const f4*)(bd + c);
+    v += r;
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    *(f4*)(out + i * 4) = v;
+  }
+}
+hipError_t launch_residual(const float* y, const float* s2, const float* b2, const float* id, const float* sd,
+                           const float* bd, float* out, size_t npix, int C, hipStream_t st) {
+  const size_t n4 = npix * C / 4;
+  hipLaunchKernelGGL(residual_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, y, s2, b2, id, sd, bd, out, n4, C);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ MaxPool 3x3 s2 p1
+__device__ __forceinline__ f4 lazy_val(f4 v, bool has, f4 sc, f4 sh, int relu) {
+  if (has) {
+    v = v * sc + sh;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  }
+  return v;
+}
+
+__global__ void maxpool_fwd_kernel(const Src in, float* __restrict__ out, uint8_t* __restrict__ idx, int Ho, int Wo,
+                                   size_t total) {
+  const int C4 = in.C / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t p = i / C4;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+    const bool has = in.scale != nullptr;
+    f4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0};
+    if (has) { sc = *(const f4*)(in.scale + c); sh = *(const f4*)(in.shift + c); }
+    const float ninf = -__builtin_huge_valf();
+    f4 best = {ninf, ninf, ninf, ninf};
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = ho * 2 - 1 + r;
+      if (h < 0 || h >= in.H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = wo * 2 - 1 + s;
+        if (w < 0 || w >= in.W) continue;
+        f4 v = lazy_val(*(const f4*)(in.ptr + ((size_t)((size_t)n * in.H + h) * in.W + w) * in.C + c), has, sc, sh, in.relu);
+        const int t = r * 3 + s;
+        if (v.x > best.x) { best.x = v.x; bi[0] = t; }
+        if (v.y > best.y) { best.y = v.y; bi[1] = t; }
+        if (v.z > best.z) { best.z = v.z; bi[2] = t; }
+        if (v.w > best.w) { best.w = v.w; bi[3] = t; }
+      }
+    }
+    *(f4*)(out + i * 4) = best;
+    if (idx) *(uchar4*)(idx + i * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+  }
+}
+hipError_t launch_maxpool_fwd(const Src& in, float* out, uint8_t* idx, int N, int Ho, int Wo, hipStream_t st) {
+  const size_t total = (size_t)N * Ho * Wo * (in.C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, in, out, idx, Ho, Wo, total);
+  return hipGetLastError();
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
+                                   const float* __restrict__ addend, const Src in, float* __restrict__ gin, int Ho,
+                                   int Wo, size_t total) {
+  const int C4 = in.C / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t p = i / C4;
+    const int w = (int)(p % in.W); p /= in.W;
+    const int h = (int)(p % in.H); const int n = (int)(p / in.H);
+    f4 g = addend ? *(const f4*)(addend + i * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+    const int ho0 = h >> 1, ho1 = (h + 1) >> 1, wo0 = w >> 1, wo1 = (w + 1) >> 1;
+    for (int a = 0; a < 2; ++a) {
+      const int ho = a ? ho1 : ho0;
+      if ((a && ho1 == ho0) || ho >= Ho) continue;
+      const int r = h - (2 * ho - 1);
+      for (int b = 0; b < 2; ++b) {
+        const int wo = b ? wo1 : wo0;
+        if ((b && wo1 == wo0) || wo >= Wo) continue;
+        const int s = w - (2 * wo - 1);
+        const size_t o = ((size_t)((size_t)n * Ho + ho) * Wo + wo) * in.C + c;
+        const uchar4 id = *(const uchar4*)(idx + o);
+        const f4 go = *(const f4*)(gout + o);
+        const int t = r * 3 + s;
+        if (id.x == t) g.x += go.x;
+        if (id.y == t) g.y += go.y;
+        if (id.z == t) g.z += go.z;
+        if (id.w == t) g.w += go.w;
+      }
+    }
+    if (in.scale && in.relu) {
+      f4 z = *(const f4*)(in.ptr + i * 4) * *(const f4*)(in.scale + c) + *(const f4*)(in.shift + c);
+      g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    }
+    *(f4*)(gin + i * 4) = g;
+  }
+}
+hipError_t launch_maxpool_bwd(const float* gout, const uint8_t* idx, const float* addend, const Src& in, float* gin,
+                              int N, int Ho, int Wo, hipStream_t st) {
+  const size_t total = (size_t)N * in.H * in.W * (in.C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, gout, idx, addend, in, gin, Ho,
+                     Wo, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BatchNorm backward
+// per-channel  dbeta = sum g,  dgamma = sum g * (y-mean)*rstd   (fp32 per thread, fp64 across)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            double* dgamma, double* dbeta, size_t npix, int C) {
+  __shared__ float red[256 * 8];
+  const int tc = C / 4;                       // threads along channels (<= 256)
+  const int tr = 256 / tc;                    // pixel rows per pass
+  const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
+  const int c = cx * 4;
+  f4 sg = {0, 0, 0, 0}, sgy = {0, 0, 0, 0};
+  if (rx < tr) {
+    const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c);
+    for (size_t p = (size_t)blockIdx.x * tr + rx; p < npix; p += (size_t)gridDim.x * tr) {
+      const f4 gv = *(const f4*)(g + p * C + c);
+      const f4 yh = (*(const f4*)(y + p * C + c) - mu) * rs;
+      sg += gv; sgy += gv * yh;
+    }
+  }
+  float* r = red + threadIdx.x * 8;
+  r[0] = sg.x; r[1] = sg.y; r[2] = sg.z; r[3] = sg.w; r[4] = sgy.x; r[5] = sgy.y; r[6] = sgy.z; r[7] = sgy.w;
+  __syncthreads();
+  for (int t = threadIdx.x; t < tc * 8; t += 256) {   // one item per (channel-quad, component)
+    const int q = t / 8, e = t % 8;
+    double s = 0.0;
+    for (int k = 0; k < tr; ++k) s += (double)red[(k * tc + q) * 8 + e];
+    if (e < 4) atomicAdd(dbeta + q * 4 + e, s); else atomicAdd(dgamma + q * 4 + (e - 4), s);
+  }
+}
+hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mean, const float* rstd, double* dgamma,
+                                double* dbeta, size_t npix, int C, hipStream_t st) {
+  if (C > 1024 || (C & 3) || (256 % (C / 4 > 256 ? 256 : C / 4))) return hipErrorInvalidValue;
+  if (C / 4 > 256) return hipErrorInvalidValue;
+  const int tr = 256 / (C / 4);
+  unsigned nb = nblocks(npix, tr * 8);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g, y, mean, rstd, dgamma, dbeta, npix, C);
+  return hipGetLastError();
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ dgamma, const double* __restrict__ dbeta, float* __restrict__ dy,
+                                    float* gamma_grad, float* beta_grad, size_t n4, int C, float invM) {
+  if (blockIdx.x == 0 && gamma_grad) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { gamma_grad[c] = (float)dgamma[c]; beta_grad[c] = (float)dbeta[c]; }
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % (size_t)C);
+    const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), gm = *(const f4*)(gamma + c);
+    f4 dg, db;
+    dg.x = (float)dgamma[c] * invM; dg.y = (float)dgamma[c + 1] * invM; dg.z = (float)dgamma[c + 2] * invM; dg.w = (float)dgamma[c + 3] * invM;
+    db.x = (float)dbeta[c] * invM; db.y = (float)dbeta[c + 1] * invM; db.z = (float)dbeta[c + 2] * invM; db.w = (float)dbeta[c + 3] * invM;
+    const f4 yh = (*(const f4*)(y + i * 4) - mu) * rs;
+    const f4 gv = *(const f4*)(g + i * 4);
+    *(f4*)(dy + i * 4) = gm * rs * (gv - db - yh * dg);
+  }
+}
+hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
+                               const double* dgamma, const double* dbeta, float* dy, float* gamma_grad, float* beta_grad,
+                               size_t npix, int C, hipStream_t st) {
+  const size_t n4 = npix * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, g, y, mean, rstd, gamma, dgamma,
+                     dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix));
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ upsample+concat gradient split
+__global__ void upsplit_prev_kernel(const float* __restrict__ dcat, int H, int W, int C0, int Ct, float* __restrict__ gprev,
+                                    const float* __restrict__ pmask, const float* __restrict__ pscale,
+                                    const float* __restrict__ pshift, size_t total) {
+  const int C4 = C0 / 4, H2 = H / 2, W2 = W / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    size_t p = i / C4;
+    const int w2 = (int)(p % W2); p /= W2;
+    const int h2 = (int)(p % H2); const int n = (int)(p / H2);
+    const float* b = dcat + ((size_t)((size_t)n * H + 2 * h2) * W + 2 * w2) * Ct + c;
+    f4 g = *(const f4*)b + *(const f4*)(b + Ct) + *(const f4*)(b + (size_t)W * Ct) + *(const f4*)(b + (size_t)W * Ct + Ct);
+    if (pmask) {
+      f4 z = *(const f4*)(pmask + i * 4);
+      if (pscale) z = z * *(const f4*)(pscale + c) + *(const f4*)(pshift + c);
+      g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    }
+    *(f4*)(gprev + i * 4) = g;
+  }
+}
+__global__ void upsplit_skip_kernel(const float* __restrict__ dcat, int C0, int C1, float* __restrict__ gskip, size_t total) {
+  const int C4 = C1 / 4, Ct = C0 + C1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const size_t p = i / C4;
+    *(f4*)(gskip + i * 4) = *(const f4*)(dcat + p * Ct + C0 + c);
+  }
+}
+hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev, const float* pmask,
+                          const float* pscale, const float* pshift, float* gskip, hipStream_t st) {
+  const size_t t0 = (size_t)N * (H / 2) * (W / 2) * (C0 / 4);
+  hipLaunchKernelGGL(upsplit_prev_kernel, dim3(nblocks(t0, 256)), dim3(256), 0, st, dcat, H, W, C0, C0 + C1, gprev, pmask,
+                     pscale, pshift, t0);
+  if (C1 > 0 && gskip) {
+    const size_t t1 = (size_t)N * H * W * (C1 / 4);
+    hipLaunchKernelGGL(upsplit_skip_kernel, dim3(nblocks(t1, 256)), dim3(256), 0, st, dcat, C0, C1, gskip, t1);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ dgrad weight repack
+// wd[ci][tap*CoutP + co] = w[co][tap*Cin + ci]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, int Cout, int Kpad, int ntaps, int Cin, float* __restrict__ wd,
+                                  int KpadD, int CoutP, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kd = (int)(i % KpadD), ci = (int)(i / KpadD);
+    const int tap = kd / CoutP, co = kd - tap * CoutP;
+    float v = 0.f;
+    if (tap < ntaps && co < Cout) v = w[(size_t)co * Kpad + tap * Cin + ci];
+    wd[i] = v;
+  }
+}
+hipError_t launch_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,
+                             hipStream_t st) {
+  const size_t total = (size_t)Cin * KpadD;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, w, Cout, Kpad, ntaps, Cin, wd, KpadD,
+                     CoutP, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ per-channel column sum (bias gradient)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, size_t npix, int C, float* out) {
+  __shared__ float red[256 * 4];
+  const int tc = C / 4, tr = 256 / tc;
+  const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
+  f4 s = {0, 0, 0, 0};
+  if (rx < tr)
+    for (size_t p = (size_t)blockIdx.x * tr + rx; p < npix; p += (size_t)gridDim.x * tr) s += *(const f4*)(g + p * C + cx * 4);
+  float* r = red + threadIdx.x * 4;
+  r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = s.w;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int q = threadIdx.x / 4, e = threadIdx.x % 4;
+    double acc = 0.0;
+    for (int k = 0; k < tr; ++k) acc += (double)red[(k * tc + q) * 4 + e];
+    atomicAdd(out + threadIdx.x, (float)acc);
+  }
+}
+hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double*, hipStream_t st) {
+  if ((C & 3) || C > 256 || (256 % (C / 4))) return hipErrorInvalidValue;
+  const int tr = 256 / (C / 4);
+  unsigned nb = nblocks(npix, tr * 16);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, g, npix, C, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam, coupled L2)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n4, size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                            float gscale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = i * 4;
+    if (o + 4 <= n) {
+      f4 pv = *(f4*)(p + o), gv = *(const f4*)(g + o) * gscale, mv = *(f4*)(m + o), vv = *(f4*)(v + o);
+      gv += wd * pv;
+      mv = mv + (1.f - b1) * (gv - mv);          // torch: m.lerp_(g, 1-b1)
+      vv = b2 * vv + (1.f - b2) * gv * gv;
+      f4 den;
+      den.x = sqrtf(vv.x) / bc2s + eps; den.y = sqrtf(vv.y) / bc2s + eps; den.z = sqrtf(vv.z) / bc2s + eps; den.w = sqrtf(vv.w) / bc2s + eps;
+      pv -= (lr / bc1) * (mv / den);
+      *(f4*)(p + o) = pv; *(f4*)(m + o) = mv; *(f4*)(v + o) = vv;
+    } else {
+      for (size_t j = o; j < n; ++j) {
+        float gj = g[j] * gscale + wd * p[j];
+        float mj = m[j] + (1.f - b1) * (gj - m[j]);
+        float vj = b2 * v[j] + (1.f - b2) * gj * gj;
+        p[j] -= (lr / bc1) * (mj / (sqrtf(vj) / bc2s + eps));
+        m[j] = mj; v[j] = vj;
+      }
+    }
+  }
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                       float wd, float bc1, float bc2, float gscale, hipStream_t st) {
+  const size_t n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, p, g, m, v, n4, n, lr, b1, b2, eps, wd, bc1,
+                     sqrtf(bc2), gscale);
+  return hipGetLastError();
+}
+
+__global__ void scale_kernel(float* __restrict__ p, size_t n, float s) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] *= s;
+}
+hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st) {
+  hipLaunchKernelGGL(scale_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, p, n, s);
+  return hipGetLastError();
+}
+
+}  // namespace uwm

@@ -1,0 +1,101 @@
+// Internal kernel-launch interface of libuwm (MI355X / gfx950 only).
+// Layout conventions:
+//   activations  NHWC fp32, channel count padded to a multiple of 4
+//   weights      [Cout_rows][Kpad] fp32, k = tap*Ctot + c  (tap = r*kw + s), Kpad % 32 == 0
+//   a "lazy" activation = raw conv output + per-channel (scale, shift[, relu]) applied by
+//   the CONSUMER when it stages the tile (BatchNorm-apply + ReLU never make their own pass)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace uwm {
+
+struct Src {                 // one (possibly lazily transformed) NHWC activation
+  const float* ptr;          // [N][H][W][C]
+  const float* scale;        // per-channel scale or nullptr (identity)
+  const float* shift;        // per-channel shift (valid when scale != nullptr)
+  int C, H, W;               // physical dims
+  int up;                    // log2 nearest-upsample factor seen by the consumer (0|1)
+  int relu;                  // max(.,0) after the affine
+};
+
+struct FastDiv {             // n / d for n*d < 2^32 (k-index arithmetic only)
+  unsigned mg, d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f; f.d = d; f.mg = (d <= 1) ? 0u : (unsigned)((0x100000000ull / d) + 1ull); return f;
+}
+
+struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (transposed gather)
+  Src s0, s1;                // channel-concat of two sources: [0,C0) from s0, [C0,Ctot) from s1
+  int C0, Ctot;
+  const float* w;            // [wrows][Kpad]
+  int wrows, Kpad, ntaps, kw;
+  int N, Ho, Wo, Cout, M;    // output [N][Ho][Wo][Cout], M = N*Ho*Wo
+  int Hl, Wl;                // logical (post-upsample) input dims used for the bounds check
+  int smul, rmul, off, sdiv; // hi_num = ho*smul + r*rmul + off ; hi = hi_num / sdiv (must divide)
+  float* out;
+  const float* bias;         // [Cout] or nullptr
+  const float* addend;       // [M][Cout] added in the epilogue or nullptr
+  const float* mask;         // [M][Cout]: out = (mask*mscale+mshift > 0) ? out : 0, or nullptr
+  const float* mscale; const float* mshift;
+  double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
+  FastDiv dv_ctot, dv_kw;
+};
+
+struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = tap*Ctot + c)
+  Src s0, s1; int C0, Ctot;
+  const float* dy;           // [M][Cout]
+  float* dw;                 // [wrows][Kpad], accumulated with float atomics
+  int wrows, Kpad, ntaps, kw;
+  int N, Ho, Wo, Cout, M;
+  int Hl, Wl, stride, pad;
+  int nsplit, msplit;        // pixel range per split (multiple of 32)
+  FastDiv dv_ctot, dv_kw;
+};
+
+// ---- launchers (all asynchronous on `st`, no host sync, no allocation) ----
+hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg = -1);
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st);
+
+hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st);
+hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,
+                              float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
+                              int C, double count, float eps, float momentum, int update_running, hipStream_t st);
+hipError_t launch_bn_eval(const float* gamma, const float* beta, const float* run_mean, const float* run_var,
+                          float* scale, float* shift, int C, float eps, hipStream_t st);
+// xn = relu(y*s2+b2 + idn), idn = id (materialised) or id*sd+bd (lazy)
+hipError_t launch_residual(const float* y, const float* s2, const float* b2, const float* id, const float* sd,
+                           const float* bd, float* out, size_t npix, int C, hipStream_t st);
+hipError_t launch_maxpool_fwd(const Src& in, float* out, uint8_t* idx, int N, int Ho, int Wo, hipStream_t st);
+// g_in = (maxpool_bwd(g_out, idx) + addend) masked by relu(in.raw*scale+shift) > 0
+hipError_t launch_maxpool_bwd(const float* gout, const uint8_t* idx, const float* addend, const Src& in,
+                              float* gin, int N, int Ho, int Wo, hipStream_t st);
+// BatchNorm backward: g = grad wrt BN output (already ReLU-masked), y = raw conv output
+hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mean, const float* rstd,
+                                double* dgamma, double* dbeta, size_t npix, int C, hipStream_t st);
+hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd,
+                               const float* gamma, const double* dgamma, const double* dbeta, float* dy,
+                               float* gamma_grad, float* beta_grad, size_t npix, int C, hipStream_t st);
+// dcat [N][H][W][C0+C1] -> gprev [N][H/2][W/2][C0] = mask(sum 2x2), gskip [N][H][W][C1] (copy)
+hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev,
+                          const float* pmask, const float* pscale, const float* pshift, float* gskip,
+                          hipStream_t st);
+hipError_t launch_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD,
+                             int CoutP, hipStream_t st);
+hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double* scratch, hipStream_t st);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                       float eps, float wd, float bc1, float bc2, float gscale, hipStream_t st);
+hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st);
+
+// loss / metrics (loss.hip)
+hipError_t launch_loss(const float* logits, int ld, const void* target, int tdtype, size_t npix_total,
+                       float w_dice, float w_bce, float smooth, float eps, double* scratch4, float* loss_out3,
+                       float* dlogits, int ldd, float grad_scale, hipStream_t st);
+hipError_t launch_stats(const float* logits, int ld, const void* target, int tdtype, int N, size_t hw,
+                        float thr, int apply_sigmoid, long long* out4, hipStream_t st);
+hipError_t launch_threshold(const float* logits, int ld, size_t npix, float thr, int apply_sigmoid,
+                            uint8_t* out, hipStream_t st);
+
+}  // namespace uwm

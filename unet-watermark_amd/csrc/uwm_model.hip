@@ -1,0 +1,680 @@
+// libuwm host side: smp.Unet(resnet18|34) graph description, parameter-arena and workspace
+// planning, forward / staged-backward orchestration (kernel launches only — no host syncs, no
+// allocation) and the C ABI declared in include/uwm.h.
+//
+// Graph follows SURVEY.md Appendix A.2/A.3 (the published smp.Unet algorithm reached from
+// /root/reference/src/models/unet_model.py:64-71); state_dict key names are smp-compatible.
+#include "../../include/uwm.h"
+#include "uwm_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace uwm;
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return 1;
+}
+#define HIPCHK(expr)                                                                           \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, \
+       hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static inline long long rup(long long v, long long a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------ model description
+struct BNL {
+  std::string name; int C; int stage;
+  long long g_off, b_off;          // param arena
+  long long rm_off, rv_off;        // buffer arena
+  size_t d_off;                    // workspace doubles: sum, sq, dgamma, dbeta (4*C)
+  size_t f_off;                    // workspace floats: mean, rstd, scale, shift (4*C)
+};
+struct ConvL {
+  std::string name; int Cin, CinP, Cout, CoutP, k, stride, pad, Kpad, KpadD, stage;
+  long long w_off, bias_off; int bn; bool dgrad;
+  size_t wd_off;                   // workspace floats: [CinP][KpadD] dgrad repack
+};
+struct BlockL { int c1, c2, cd; };
+struct DecL { int c1, c2, C0, C1; };
+
+struct Plan {                       // workspace layout for one (N,H,W,training)
+  int N = 0, H = 0, W = 0, training = -1;
+  size_t bytes = 0;
+  size_t x4 = 0, pool = 0, pool_idx = 0, g_pool = 0, tmp = 0, loss_scr = 0;
+  std::vector<size_t> y, g;         // per conv: raw output / its gradient buffer (float offsets)
+  std::vector<size_t> xn, gx;       // per encoder block: residual output / its gradient
+  std::vector<size_t> dcat, gskip;  // per decoder block
+  size_t stat_d = 0, stat_d_count = 0;   // BN double region
+};
+
+struct uwm_model {
+  uwm_unet_desc desc;
+  std::vector<ConvL> convs;
+  std::vector<BNL> bns;
+  std::vector<std::vector<BlockL>> stages;   // 4 encoder stages
+  std::vector<DecL> dec;
+  int stem = -1, head = -1, CP = 4, CinP = 4;
+  long long param_floats = 0, buffer_floats = 0, param_count = 0;
+  long long stage_begin[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<uwm_tensor_info> infos;
+  float *params = nullptr, *grads = nullptr, *buffers = nullptr;
+  size_t fixed_floats = 0;           // fixed workspace region (BN scratch + dgrad packs), in floats
+  Plan plan;
+  bool have_fwd = false;
+};
+
+static int add_bn(uwm_model* m, const std::string& name, int C, int stage) {
+  BNL b; b.name = name; b.C = C; b.stage = stage; b.g_off = b.b_off = b.rm_off = b.rv_off = -1; b.d_off = b.f_off = 0;
+  m->bns.push_back(b); return (int)m->bns.size() - 1;
+}
+static int add_conv(uwm_model* m, const std::string& name, int Cin, int Cout, int k, int stride, int pad, int stage,
+                    bool dgrad, const std::string& bn_name, bool bias = false) {
+  ConvL c; c.name = name; c.Cin = Cin; c.CinP = (int)rup(Cin, 4); c.Cout = Cout; c.CoutP = (int)rup(Cout, 4);
+  c.k = k; c.stride = stride; c.pad = pad; c.stage = stage; c.dgrad = dgrad;
+  c.Kpad = (int)rup((long long)k * k * c.CinP, 32);
+  c.KpadD = (int)rup((long long)k * k * c.CoutP, 32);
+  c.w_off = -1; c.bias_off = bias ? 0 : -1; c.wd_off = 0;
+  c.bn = bn_name.empty() ? -1 : add_bn(m, bn_name, Cout, stage);
+  m->convs.push_back(c); return (int)m->convs.size() - 1;
+}
+
+static void push_info(uwm_model* m, const std::string& name, int kind, int arena, long long off, int ndim,
+                      const long long* shape, const long long* stride) {
+  uwm_tensor_info t; memset(&t, 0, sizeof(t));
+  snprintf(t.name, sizeof(t.name), "%s", name.c_str());
+  t.kind = kind; t.arena = arena; t.ndim = ndim; t.offset = off;
+  for (int i = 0; i < ndim; ++i) { t.shape[i] = shape[i]; t.stride[i] = stride[i]; }
+  m->infos.push_back(t);
+}
+
+static int build_model(uwm_model* m) {
+  const uwm_unet_desc& d = m->desc;
+  int nb[4];
+  if (d.encoder == UWM_ENC_RESNET18) { nb[0] = 2; nb[1] = 2; nb[2] = 2; nb[3] = 2; }
+  else if (d.encoder == UWM_ENC_RESNET34) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; }
+  else return fail("unsupported encoder %d (supported: resnet18, resnet34)", d.encoder);
+  if (d.in_channels < 1 || d.in_channels > 4) return fail("in_channels must be 1..4, got %d", d.in_channels);
+  if (d.classes < 1 || d.classes > 4) return fail("classes must be 1..4, got %d", d.classes);
+  for (int i = 0; i < 5; ++i)
+    if (d.decoder_channels[i] < 4 || (d.decoder_channels[i] & 3)) return fail("decoder_channels[%d]=%d must be a positive multiple of 4", i, d.decoder_channels[i]);
+  m->CP = (int)rup(d.classes, 4); m->CinP = (int)rup(d.in_channels, 4);
+  const int widths[4] = {64, 128, 256, 512};
+  // backward stages: 0 head+decoder, 1 layer4, 2 layer3, 3 layer2, 4 layer1+stem
+  m->stem = add_conv(m, "encoder.conv1", d.in_channels, 64, 7, 2, 3, 4, false, "encoder.bn1");
+  int cin = 64;
+  m->stages.resize(4);
+  for (int s = 0; s < 4; ++s) {
+    const int stage = 4 - s;
+    for (int b = 0; b < nb[s]; ++b) {
+      const int stride = (b == 0 && s > 0) ? 2 : 1;
+      char pre[64]; snprintf(pre, sizeof(pre), "encoder.layer%d.%d", s + 1, b);
+      BlockL bl;
+      bl.c1 = add_conv(m, std::string(pre) + ".conv1", cin, widths[s], 3, stride, 1, stage, true, std::string(pre) + ".bn1");
+      bl.c2 = add_conv(m, std::string(pre) + ".conv2", widths[s], widths[s], 3, 1, 1, stage, true, std::string(pre) + ".bn2");
+      bl.cd = -1;
+      if (stride != 1 || cin != widths[s])
+        bl.cd = add_conv(m, std::string(pre) + ".downsample.0", cin, widths[s], 1, stride, 0, stage, true, std::string(pre) + ".downsample.1");
+      m->stages[s].push_back(bl);
+      cin = widths[s];
+    }
+  }
+  const int encc[5] = {512, 256, 128, 64, 64};
+  int prev = encc[0];
+  for (int i = 0; i < 5; ++i) {
+    const int skip = i < 4 ? encc[i + 1] : 0, out = d.decoder_channels[i];
+    char pre[64]; snprintf(pre, sizeof(pre), "decoder.blocks.%d", i);
+    DecL dl; dl.C0 = prev; dl.C1 = skip;
+    dl.c1 = add_conv(m, std::string(pre) + ".conv1.0", prev + skip, out, 3, 1, 1, 0, true, std::string(pre) + ".conv1.1");
+    dl.c2 = add_conv(m, std::string(pre) + ".conv2.0", out, out, 3, 1, 1, 0, true, std::string(pre) + ".conv2.1");
+    m->dec.push_back(dl);
+    prev = out;
+  }
+  m->head = add_conv(m, "segmentation_head.0", prev, d.classes, 3, 1, 1, 0, true, "", true);
+
+  // ---- parameter arena: grouped by backward stage so each stage's gradients are one range
+  long long off = 0;
+  for (int st = 0; st < 5; ++st) {
+    m->stage_begin[st] = off;
+    for (auto& c : m->convs) if (c.stage == st) {
+      c.w_off = off; off += (long long)c.Cout * c.Kpad;
+      if (c.bias_off == 0) { c.bias_off = off; off += c.CoutP; }
+    }
+    for (auto& b : m->bns) if (b.stage == st) { b.g_off = off; off += b.C; b.b_off = off; off += b.C; }
+    off = rup(off, 64);
+  }
+  m->stage_begin[5] = off;
+  m->param_floats = off;
+  long long boff = 0;
+  for (auto& b : m->bns) { b.rm_off = boff; boff += b.C; b.rv_off = boff; boff += b.C; }
+  m->buffer_floats = rup(boff, 64);
+
+  // ---- fixed workspace region: BN scratch, dgrad weight repacks
+  size_t dcount = 0;
+  for (auto& b : m->bns) { b.d_off = dcount; dcount += 4 * (size_t)b.C; }
+  size_t f = dcount * 2;                        // doubles first (in float units)
+  f = (size_t)rup((long long)f, 64);
+  for (auto& b : m->bns) { b.f_off = f; f += 4 * (size_t)b.C; }
+  f = (size_t)rup((long long)f, 64);
+  for (auto& c : m->convs) if (c.dgrad) { c.wd_off = f; f += (size_t)c.CinP * c.KpadD; f = (size_t)rup((long long)f, 64); }
+  m->fixed_floats = f;
+
+  // ---- tensor infos in smp state_dict order
+  m->param_count = 0;
+  auto conv_info = [&](const ConvL& c) {
+    long long shape[4] = {c.Cout, c.Cin, c.k, c.k};
+    long long stride[4] = {c.Kpad, 1, (long long)c.k * c.CinP, c.CinP};
+    push_info(m, c.name + ".weight", UWM_KIND_CONV_W, UWM_ARENA_PARAM, c.w_off, 4, shape, stride);
+    m->param_count += (long long)c.Cout * c.Cin * c.k * c.k;
+    if (c.bias_off >= 0) {
+      long long s1[1] = {c.Cout}, st1[1] = {1};
+      push_info(m, c.name + ".bias", UWM_KIND_BIAS, UWM_ARENA_PARAM, c.bias_off, 1, s1, st1);
+      m->param_count += c.Cout;
+    }
+  };
+  auto bn_info = [&](const BNL& b) {
+    long long s1[1] = {b.C}, st1[1] = {1};
+    push_info(m, b.name + ".weight", UWM_KIND_BN_GAMMA, UWM_ARENA_PARAM, b.g_off, 1, s1, st1);
+    push_info(m, b.name + ".bias", UWM_KIND_BN_BETA, UWM_ARENA_PARAM, b.b_off, 1, s1, st1);
+    push_info(m, b.name + ".running_mean", UWM_KIND_BN_MEAN, UWM_ARENA_BUFFER, b.rm_off, 1, s1, st1);
+    push_info(m, b.name + ".running_var", UWM_KIND_BN_VAR, UWM_ARENA_BUFFER, b.rv_off, 1, s1, st1);
+    m->param_count += 2LL * b.C;
+  };
+  for (auto& c : m->convs) { conv_info(c); if (c.bn >= 0) bn_info(m->bns[c.bn]); }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ workspace plan
+static void make_plan(uwm_model* m, int N, int H, int W, int training) {
+  Plan p; p.N = N; p.H = H; p.W = W; p.training = training;
+  size_t off = m->fixed_floats;
+  auto alloc = [&](size_t floats) { size_t o = off; off += (size_t)rup((long long)floats, 64); return o; };
+  const size_t nc = m->convs.size();
+  p.y.assign(nc, 0); p.g.assign(nc, 0);
+  p.stat_d = 0; p.stat_d_count = 0; for (auto& b : m->bns) p.stat_d_count += 4 * (size_t)b.C;
+  p.loss_scr = alloc(64);
+  p.x4 = alloc((size_t)N * H * W * m->CinP);
+  int h = H / 2, w = W / 2;
+  p.y[m->stem] = alloc((size_t)N * h * w * 64);
+  h /= 2; w /= 2;
+  p.pool = alloc((size_t)N * h * w * 64);
+  p.pool_idx = alloc((size_t)N * h * w * 64 / 4 + 64);
+  size_t nblk = 0; for (auto& s : m->stages) nblk += s.size();
+  p.xn.assign(nblk, 0); p.gx.assign(nblk, 0);
+  size_t bi = 0; size_t max_in = (size_t)N * h * w * 64;
+  std::vector<int> sh(4), sw(4);
+  for (int s = 0; s < 4; ++s) {
+    for (auto& bl : m->stages[s]) {
+      const ConvL& c1 = m->convs[bl.c1];
+      h /= c1.stride; w /= c1.stride;
+      const size_t sz = (size_t)N * h * w * c1.Cout;
+      p.y[bl.c1] = alloc(sz); p.y[bl.c2] = alloc(sz);
+      if (bl.cd >= 0) p.y[bl.cd] = alloc(sz);
+      p.xn[bi++] = alloc(sz);
+      if (sz > max_in) max_in = sz;
+    }
+    sh[s] = h; sw[s] = w;
+  }
+  for (size_t i = 0; i < m->dec.size(); ++i) {
+    h *= 2; w *= 2;
+    const size_t sz = (size_t)N * h * w * m->convs[m->dec[i].c1].Cout;
+    p.y[m->dec[i].c1] = alloc(sz); p.y[m->dec[i].c2] = alloc(sz);
+  }
+  if (training) {
+    // gradient buffers (same shapes as their activations)
+    h = H / 2; w = W / 2;
+    p.g[m->stem] = alloc((size_t)N * h * w * 64);
+    h /= 2; w /= 2;
+    p.g_pool = alloc((size_t)N * h * w * 64);
+    bi = 0;
+    for (int s = 0; s < 4; ++s)
+      for (auto& bl : m->stages[s]) {
+        const ConvL& c1 = m->convs[bl.c1];
+        h /= c1.stride; w /= c1.stride;
+        const size_t sz = (size_t)N * h * w * c1.Cout;
+        p.g[bl.c1] = alloc(sz); p.g[bl.c2] = alloc(sz);
+        if (bl.cd >= 0) p.g[bl.cd] = alloc(sz);
+        p.gx[bi++] = alloc(sz);
+      }
+    p.tmp = alloc(max_in);
+    p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
+    for (size_t i = 0; i < m->dec.size(); ++i) {
+      h *= 2; w *= 2;
+      const DecL& d = m->dec[i];
+      const size_t sz = (size_t)N * h * w * m->convs[d.c1].Cout;
+      p.g[d.c1] = alloc(sz); p.g[d.c2] = alloc(sz);
+      p.dcat[i] = alloc((size_t)N * h * w * (d.C0 + d.C1));
+      if (d.C1 > 0) p.gskip[i] = alloc((size_t)N * h * w * d.C1);
+    }
+  }
+  p.bytes = off * sizeof(float);
+  m->plan = p;
+}
+
+// ------------------------------------------------------------------------------ launch helpers
+struct Ctx {
+  uwm_model* m; float* ws; hipStream_t st; int N;
+  float* F(size_t off) const { return ws + off; }
+  double* D(size_t doff) const { return (double*)ws + doff; }
+};
+static Src mk_src(const float* ptr, int C, int H, int W, const float* scale = nullptr, const float* shift = nullptr,
+                  int relu = 0, int up = 0) {
+  Src s; s.ptr = ptr; s.scale = scale; s.shift = shift; s.C = C; s.H = H; s.W = W; s.up = up; s.relu = relu; return s;
+}
+static Src lazy_src(const Ctx& c, int conv, int H, int W, int relu = 1, int up = 0) {
+  const ConvL& cv = c.m->convs[conv];
+  const BNL& b = c.m->bns[cv.bn];
+  return mk_src(c.F(c.m->plan.y[conv]), cv.CoutP, H, W, c.F(b.f_off) + 2 * b.C, c.F(b.f_off) + 3 * b.C, relu, up);
+}
+
+static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s1, int Ho, int Wo, float* out,
+                               bool stats, int cfg = -1) {
+  const ConvL& cv = c.m->convs[ci];
+  ConvArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = s0; a.C0 = s0.C;
+  if (s1) { a.s1 = *s1; a.Ctot = s0.C + s1->C; } else { a.s1 = s0; a.Ctot = s0.C; }
+  a.w = c.m->params + cv.w_off; a.wrows = cv.Cout; a.Kpad = cv.Kpad; a.ntaps = cv.k * cv.k; a.kw = cv.k;
+  a.N = c.N; a.Ho = Ho; a.Wo = Wo; a.Cout = cv.CoutP; a.M = c.N * Ho * Wo;
+  a.Hl = s0.H << s0.up; a.Wl = s0.W << s0.up;
+  a.smul = cv.stride; a.rmul = 1; a.off = -cv.pad; a.sdiv = 1;
+  a.out = out; a.bias = cv.bias_off >= 0 ? c.m->params + cv.bias_off : nullptr;
+  if (stats && cv.bn >= 0) { const BNL& b = c.m->bns[cv.bn]; a.ssum = c.D(b.d_off); a.ssq = c.D(b.d_off) + b.C; }
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  return launch_conv(a, c.st, cfg);
+}
+
+// dX = dgrad(dY) (+addend) (*mask)
+static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int Wo, int Hin, int Win, float* dx,
+                            const float* addend, const float* mask, const float* mscale, const float* mshift) {
+  const ConvL& cv = c.m->convs[ci];
+  ConvArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = mk_src(dy, cv.CoutP, Ho, Wo); a.s1 = a.s0; a.C0 = cv.CoutP; a.Ctot = cv.CoutP;
+  a.w = c.F(cv.wd_off); a.wrows = cv.CinP; a.Kpad = cv.KpadD; a.ntaps = cv.k * cv.k; a.kw = cv.k;
+  a.N = c.N; a.Ho = Hin; a.Wo = Win; a.Cout = cv.CinP; a.M = c.N * Hin * Win;
+  a.Hl = Ho; a.Wl = Wo; a.smul = 1; a.rmul = -1; a.off = cv.pad; a.sdiv = cv.stride;
+  a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  return launch_conv(a, c.st);
+}
+
+static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, const float* dy, int Ho, int Wo) {
+  const ConvL& cv = c.m->convs[ci];
+  WgradArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = s0; a.C0 = s0.C;
+  if (s1) { a.s1 = *s1; a.Ctot = s0.C + s1->C; } else { a.s1 = s0; a.Ctot = s0.C; }
+  a.dy = dy; a.dw = c.m->grads + cv.w_off; a.wrows = cv.Cout; a.Kpad = cv.Kpad; a.ntaps = cv.k * cv.k; a.kw = cv.k;
+  a.N = c.N; a.Ho = Ho; a.Wo = Wo; a.Cout = cv.CoutP; a.M = c.N * Ho * Wo;
+  a.Hl = s0.H << s0.up; a.Wl = s0.W << s0.up; a.stride = cv.stride; a.pad = cv.pad;
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  return launch_wgrad(a, c.st);
+}
+
+static hipError_t run_bn_finalize(const Ctx& c, int bi, size_t count, int training) {
+  uwm_model* m = c.m; const BNL& b = m->bns[bi];
+  float* f = c.F(b.f_off);
+  if (training)
+    return launch_bn_finalize(c.D(b.d_off), c.D(b.d_off) + b.C, m->params + b.g_off, m->params + b.b_off,
+                              m->buffers + b.rm_off, m->buffers + b.rv_off, f, f + b.C, f + 2 * b.C, f + 3 * b.C, b.C,
+                              (double)count, m->desc.bn_eps, m->desc.bn_momentum, 1, c.st);
+  return launch_bn_eval(m->params + b.g_off, m->params + b.b_off, m->buffers + b.rm_off, m->buffers + b.rv_off,
+                        f + 2 * b.C, f + 3 * b.C, b.C, m->desc.bn_eps, c.st);
+}
+
+// g (masked grad wrt BN output) -> dy ; also writes gamma/beta gradients
+static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, size_t npix) {
+  uwm_model* m = c.m; const ConvL& cv = m->convs[ci]; const BNL& b = m->bns[cv.bn];
+  const float* f = c.F(b.f_off); const float* y = c.F(m->plan.y[ci]);
+  double* dg = c.D(b.d_off) + 2 * b.C; double* db = c.D(b.d_off) + 3 * b.C;
+  hipError_t e = launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
+  if (e != hipSuccess) return e;
+  return launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, dg, db, dy, m->grads + b.g_off, m->grads + b.b_off,
+                             npix, b.C, c.st);
+}
+
+#define LCHK(expr)                                                                                     \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("launch failed: %s at %s:%d (%s)",  \
+       hipGetErrorString(e_), __FILE__, __LINE__, #expr); } while (0)
+
+// ------------------------------------------------------------------------------ forward
+static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, int N, int H, int W, int training,
+                      hipStream_t st) {
+  const Plan& p = m->plan;
+  Ctx c{m, ws, st, N};
+  if (training) HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
+  LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
+  // eval: all BN scale/shift come from running stats and are known up front
+  if (!training) for (size_t i = 0; i < m->bns.size(); ++i) LCHK(run_bn_finalize(c, (int)i, 1, 0));
+  auto conv_bn = [&](int ci, const Src& s0, const Src* s1, int Ho, int Wo) -> int {
+    LCHK(run_conv_fwd(c, ci, s0, s1, Ho, Wo, c.F(p.y[ci]), training != 0));
+    if (training) LCHK(run_bn_finalize(c, m->convs[ci].bn, (size_t)N * Ho * Wo, 1));
+    return 0;
+  };
+  int h = H / 2, w = W / 2;
+  Src x4 = mk_src(c.F(p.x4), m->CinP, H, W);
+  if (conv_bn(m->stem, x4, nullptr, h, w)) return 1;
+  Src f1 = lazy_src(c, m->stem, h, w);
+  const int h1 = h, w1 = w;
+  h /= 2; w /= 2;
+  LCHK(launch_maxpool_fwd(f1, c.F(p.pool), training ? (uint8_t*)c.F(p.pool_idx) : nullptr, N, h, w, st));
+  Src cur = mk_src(c.F(p.pool), 64, h, w);
+  Src feats[4];
+  size_t bi = 0;
+  for (int s = 0; s < 4; ++s) {
+    for (auto& bl : m->stages[s]) {
+      const ConvL& c1 = m->convs[bl.c1];
+      const int ho = h / c1.stride, wo = w / c1.stride;
+      if (conv_bn(bl.c1, cur, nullptr, ho, wo)) return 1;
+      Src a1 = lazy_src(c, bl.c1, ho, wo);
+      if (conv_bn(bl.c2, a1, nullptr, ho, wo)) return 1;
+      const BNL& b2 = m->bns[m->convs[bl.c2].bn];
+      const float *idp = cur.ptr, *sd = nullptr, *bd = nullptr;
+      if (bl.cd >= 0) {
+        if (conv_bn(bl.cd, cur, nullptr, ho, wo)) return 1;
+        const BNL& bdn = m->bns[m->convs[bl.cd].bn];
+        idp = c.F(p.y[bl.cd]); sd = c.F(bdn.f_off) + 2 * bdn.C; bd = c.F(bdn.f_off) + 3 * bdn.C;
+      }
+      LCHK(launch_residual(c.F(p.y[bl.c2]), c.F(b2.f_off) + 2 * b2.C, c.F(b2.f_off) + 3 * b2.C, idp, sd, bd,
+                           c.F(p.xn[bi]), (size_t)N * ho * wo, c1.Cout, st));
+      h = ho; w = wo;
+      cur = mk_src(c.F(p.xn[bi]), c1.Cout, h, w);
+      ++bi;
+    }
+    feats[s] = cur;
+  }
+  Src d = feats[3];
+  for (size_t i = 0; i < m->dec.size(); ++i) {
+    const DecL& dl = m->dec[i];
+    Src up = d; up.up = 1;
+    h *= 2; w *= 2;
+    Src skip; const Src* sp = nullptr;
+    if (i < 3) { skip = feats[2 - i]; sp = &skip; }
+    else if (i == 3) { skip = f1; sp = &skip; }
+    if (sp && (skip.H != h || skip.W != w)) return fail("internal: skip shape mismatch at decoder block %d", (int)i);
+    if (conv_bn(dl.c1, up, sp, h, w)) return 1;
+    Src a1 = lazy_src(c, dl.c1, h, w);
+    if (conv_bn(dl.c2, a1, nullptr, h, w)) return 1;
+    d = lazy_src(c, dl.c2, h, w);
+  }
+  (void)h1; (void)w1;
+  LCHK(run_conv_fwd(c, m->head, d, nullptr, h, w, logits, false));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ backward
+static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, int se, hipStream_t st) {
+  const Plan& p = m->plan;
+  const int N = p.N, H = p.H, W = p.W;
+  Ctx c{m, ws, st, N};
+  // geometry
+  const int h1 = H / 2, w1 = W / 2;          // f1
+  int sh[4], sw[4];
+  { int h = H / 4, w = W / 4; for (int s = 0; s < 4; ++s) { if (s > 0) { h /= 2; w /= 2; } sh[s] = h; sw[s] = w; } }
+  std::vector<size_t> first_blk(4); { size_t b = 0; for (int s = 0; s < 4; ++s) { first_blk[s] = b; b += m->stages[s].size(); } }
+  auto feat_src = [&](int s) {      // materialised output of encoder stage s (f2..f5)
+    const size_t lb = first_blk[s] + m->stages[s].size() - 1;
+    return mk_src(c.F(p.xn[lb]), m->convs[m->stages[s].back().c1].Cout, sh[s], sw[s]);
+  };
+  Src f1 = lazy_src(c, m->stem, h1, w1);
+
+  if (sb <= 0 && se > 0) {
+    HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
+    // zero dgamma/dbeta halves of every BN's double scratch
+    for (auto& b : m->bns) HIPCHK(hipMemsetAsync(c.D(b.d_off) + 2 * b.C, 0, 2 * (size_t)b.C * sizeof(double), st));
+    for (auto& cv : m->convs)
+      if (cv.dgrad)
+        LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
+                               cv.CoutP, st));
+    // ---------------- head
+    const ConvL& hd = m->convs[m->head];
+    const DecL& dl4 = m->dec.back();
+    Src d4 = lazy_src(c, dl4.c2, H, W);
+    LCHK(run_wgrad(c, m->head, d4, nullptr, dlogits, H, W));
+    LCHK(launch_colsum(dlogits, (size_t)N * H * W, hd.CoutP, m->grads + hd.bias_off, nullptr, st));
+    LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[dl4.c2]), nullptr, d4.ptr, d4.scale, d4.shift));
+    // ---------------- decoder blocks, last to first
+    int h = H, w = W;
+    for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
+      const DecL& dl = m->dec[i];
+      const size_t npix = (size_t)N * h * w;
+      LCHK(run_bn_bwd(c, dl.c2, c.F(p.g[dl.c2]), c.F(p.g[dl.c2]), npix));
+      Src a1 = lazy_src(c, dl.c1, h, w);
+      LCHK(run_wgrad(c, dl.c2, a1, nullptr, c.F(p.g[dl.c2]), h, w));
+      LCHK(run_dgrad(c, dl.c2, c.F(p.g[dl.c2]), h, w, h, w, c.F(p.g[dl.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
+      LCHK(run_bn_bwd(c, dl.c1, c.F(p.g[dl.c1]), c.F(p.g[dl.c1]), npix));
+      // the block's input: cat(up(prev), skip)
+      Src prev = (i == 0) ? feat_src(3) : lazy_src(c, m->dec[i - 1].c2, h / 2, w / 2);
+      prev.up = 1;
+      Src skip; const Src* sp = nullptr;
+      if (i < 3) { skip = feat_src(2 - i); sp = &skip; } else if (i == 3) { skip = f1; sp = &skip; }
+      LCHK(run_wgrad(c, dl.c1, prev, sp, c.F(p.g[dl.c1]), h, w));
+      LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, c.F(p.dcat[i]), nullptr, nullptr, nullptr, nullptr));
+      float* gprev = (i == 0) ? c.F(p.gx[first_blk[3] + m->stages[3].size() - 1]) : c.F(p.g[m->dec[i - 1].c2]);
+      LCHK(launch_upsplit(c.F(p.dcat[i]), N, h, w, dl.C0, dl.C1, gprev, prev.ptr, prev.scale, prev.shift,
+                          dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, st));
+      h /= 2; w /= 2;
+    }
+  }
+  // ---------------- encoder stages: backward stage k handles encoder stage s = 4 - k
+  for (int k = (sb < 1 ? 1 : sb); k < se && k <= 4; ++k) {
+    const int s = 4 - k;
+    const int h = sh[s], w = sw[s];
+    const size_t npix = (size_t)N * h * w;
+    for (int b = (int)m->stages[s].size() - 1; b >= 0; --b) {
+      const BlockL& bl = m->stages[s][b];
+      const size_t bi = first_blk[s] + b;
+      const float* dz = c.F(p.gx[bi]);                       // masked grad wrt the block output
+      LCHK(run_bn_bwd(c, bl.c2, dz, c.F(p.g[bl.c2]), npix));
+      if (bl.cd >= 0) LCHK(run_bn_bwd(c, bl.cd, dz, c.F(p.g[bl.cd]), npix));
+      Src a1 = lazy_src(c, bl.c1, h, w);
+      LCHK(run_wgrad(c, bl.c2, a1, nullptr, c.F(p.g[bl.c2]), h, w));
+      LCHK(run_dgrad(c, bl.c2, c.F(p.g[bl.c2]), h, w, h, w, c.F(p.g[bl.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
+      LCHK(run_bn_bwd(c, bl.c1, c.F(p.g[bl.c1]), c.F(p.g[bl.c1]), npix));
+      // block input
+      const ConvL& c1 = m->convs[bl.c1];
+      const int hin = h * c1.stride, win = w * c1.stride;
+      Src in; float* gin; const float* in_mask;
+      if (b > 0) { in = mk_src(c.F(p.xn[bi - 1]), c1.CinP, hin, win); gin = c.F(p.gx[bi - 1]); in_mask = in.ptr; }
+      else if (s > 0) { in = feat_src(s - 1); gin = c.F(p.gx[first_blk[s] - 1]); in_mask = in.ptr; }
+      else { in = mk_src(c.F(p.pool), 64, hin, win); gin = c.F(p.g_pool); in_mask = nullptr; }
+      LCHK(run_wgrad(c, bl.c1, in, nullptr, c.F(p.g[bl.c1]), h, w));
+      const float* addend;
+      if (bl.cd >= 0) {
+        LCHK(run_wgrad(c, bl.cd, in, nullptr, c.F(p.g[bl.cd]), h, w));
+        // skip-connection gradient from the decoder for this feature (f2,f3,f4 <- dec blocks 2,1,0)
+        const float* gs = (b == 0 && s > 0) ? c.F(p.gskip[3 - s]) : nullptr;
+        LCHK(run_dgrad(c, bl.cd, c.F(p.g[bl.cd]), h, w, hin, win, c.F(p.tmp), gs, nullptr, nullptr, nullptr));
+        addend = c.F(p.tmp);
+      } else {
+        addend = dz;                                         // identity shortcut
+      }
+      LCHK(run_dgrad(c, bl.c1, c.F(p.g[bl.c1]), h, w, hin, win, gin, addend, in_mask, nullptr, nullptr));
+    }
+    if (s == 0) {
+      // maxpool backward (+ decoder skip gradient for f1) -> stem BN backward -> stem wgrad
+      LCHK(launch_maxpool_bwd(c.F(p.g_pool), (const uint8_t*)c.F(p.pool_idx), c.F(p.gskip[3]), f1, c.F(p.g[m->stem]), N,
+                              sh[0], sw[0], st));
+      LCHK(run_bn_bwd(c, m->stem, c.F(p.g[m->stem]), c.F(p.g[m->stem]), (size_t)N * h1 * w1));
+      Src x4 = mk_src(c.F(p.x4), m->CinP, H, W);
+      LCHK(run_wgrad(c, m->stem, x4, nullptr, c.F(p.g[m->stem]), h1, w1));
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* uwm_last_error(void) { return g_err; }
+int uwm_version(void) { return 1; }
+
+int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
+  if (!desc || !out) return fail("uwm_create: null argument");
+  uwm_model* m = new uwm_model();
+  m->desc = *desc;
+  if (m->desc.bn_eps <= 0.f) m->desc.bn_eps = 1e-5f;
+  if (m->desc.bn_momentum <= 0.f) m->desc.bn_momentum = 0.1f;
+  if (build_model(m)) { delete m; return 1; }
+  *out = m; return 0;
+}
+void uwm_destroy(uwm_handle h) { delete h; }
+
+long long uwm_param_arena_floats(uwm_handle h) { return h ? h->param_floats : 0; }
+long long uwm_buffer_arena_floats(uwm_handle h) { return h ? h->buffer_floats : 0; }
+long long uwm_param_count(uwm_handle h) { return h ? h->param_count : 0; }
+int uwm_num_tensors(uwm_handle h) { return h ? (int)h->infos.size() : 0; }
+int uwm_tensor_info_get(uwm_handle h, int i, uwm_tensor_info* out) {
+  if (!h || !out || i < 0 || i >= (int)h->infos.size()) return fail("uwm_tensor_info_get: bad index %d", i);
+  *out = h->infos[i]; return 0;
+}
+int uwm_logits_channels(uwm_handle h) { return h ? h->CP : 0; }
+int uwm_num_stages(uwm_handle) { return 5; }
+int uwm_stage_range(uwm_handle h, int stage, long long* b, long long* e) {
+  if (!h || stage < 0 || stage >= 5 || !b || !e) return fail("uwm_stage_range: bad stage %d", stage);
+  *b = h->stage_begin[stage]; *e = h->stage_begin[stage + 1]; return 0;
+}
+int uwm_bind(uwm_handle h, float* params, float* grads, float* buffers) {
+  if (!h || !params || !buffers) return fail("uwm_bind: params and buffers must be non-null");
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)buffers) & 15) return fail("uwm_bind: arenas must be 16-byte aligned");
+  h->params = params; h->grads = grads; h->buffers = buffers; return 0;
+}
+
+static int check_shape(int N, int H, int W) {
+  if (N < 1) return fail("batch size must be >= 1, got %d", N);
+  if (H < 32 || W < 32 || (H % 32) || (W % 32))
+    return fail("Wrong input shape height=%d, width=%d. Expected image height and width divisible by 32.", H, W);
+  if ((long long)N * H * W >= (1LL << 31) / 16) return fail("N*H*W too large for 32-bit pixel indexing: %lld", (long long)N * H * W);
+  return 0;
+}
+
+size_t uwm_workspace_bytes(uwm_handle h, int N, int H, int W, int training) {
+  if (!h || check_shape(N, H, W)) return 0;
+  if (h->plan.N != N || h->plan.H != H || h->plan.W != W || h->plan.training != (training ? 1 : 0)) {
+    make_plan(h, N, H, W, training ? 1 : 0);
+    h->have_fwd = false;
+  }
+  return h->plan.bytes;
+}
+
+int uwm_forward(uwm_handle h, const float* x, float* logits, void* ws, size_t ws_bytes, int N, int H, int W, int training,
+                uwm_stream stream) {
+  if (!h || !x || !logits || !ws) return fail("uwm_forward: null argument");
+  if (!h->params || !h->buffers) return fail("uwm_forward: call uwm_bind first");
+  if (check_shape(N, H, W)) return 1;
+  if (((uintptr_t)x | (uintptr_t)logits | (uintptr_t)ws) & 15) return fail("uwm_forward: pointers must be 16-byte aligned");
+  const size_t need = uwm_workspace_bytes(h, N, H, W, training);
+  if (ws_bytes < need) return fail("uwm_forward: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+  h->have_fwd = false;
+  if (do_forward(h, x, logits, (float*)ws, N, H, W, training ? 1 : 0, (hipStream_t)stream)) return 1;
+  h->have_fwd = training != 0;
+  return 0;
+}
+
+int uwm_backward(uwm_handle h, const float* dlogits, void* ws, int sb, int se, uwm_stream stream) {
+  if (!h || !dlogits || !ws) return fail("uwm_backward: null argument");
+  if (!h->grads) return fail("uwm_backward: no gradient arena bound");
+  if (!h->have_fwd) return fail("uwm_backward: no training-mode forward is held in the workspace");
+  if (sb < 0 || se > 5 || sb >= se) return fail("uwm_backward: bad stage range [%d,%d)", sb, se);
+  return do_backward(h, dlogits, (float*)ws, sb, se, (hipStream_t)stream);
+}
+
+int uwm_loss(const float* logits, int ld, const void* target, int tdt, long long npix, float w_dice, float w_bce,
+             float smooth, float eps, void* scratch, float* loss_out, float* dlogits, int ldd, float grad_scale,
+             uwm_stream stream) {
+  if (!logits || !target || !scratch || !loss_out || npix <= 0 || ld < 1) return fail("uwm_loss: bad argument");
+  if (tdt < 0 || tdt > 3) return fail("uwm_loss: unsupported target dtype %d", tdt);
+  if (dlogits && ldd < 1) return fail("uwm_loss: bad dlogits stride");
+  LCHK(launch_loss(logits, ld, target, tdt, (size_t)npix, w_dice, w_bce, smooth, eps, (double*)scratch, loss_out, dlogits,
+                   ldd, grad_scale, (hipStream_t)stream));
+  return 0;
+}
+int uwm_stats(const float* logits, int ld, const void* target, int tdt, int N, long long hw, float thr, int sig,
+              long long* out, uwm_stream stream) {
+  if (!logits || !target || !out || N < 1 || hw < 1) return fail("uwm_stats: bad argument");
+  if (tdt < 0 || tdt > 3) return fail("uwm_stats: unsupported target dtype %d", tdt);
+  LCHK(launch_stats(logits, ld, target, tdt, N, (size_t)hw, thr, sig, out, (hipStream_t)stream));
+  return 0;
+}
+int uwm_threshold(const float* logits, int ld, long long npix, float thr, int sig, uint8_t* mask, uwm_stream stream) {
+  if (!logits || !mask || npix < 1) return fail("uwm_threshold: bad argument");
+  LCHK(launch_threshold(logits, ld, (size_t)npix, thr, sig, mask, (hipStream_t)stream));
+  return 0;
+}
+int uwm_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+             long long step, float gscale, uwm_stream stream) {
+  if (!p || !g || !m || !v || n < 1 || step < 1) return fail("uwm_adam: bad argument");
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  LCHK(launch_adam(p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream));
+  return 0;
+}
+int uwm_scale(float* p, long long n, float s, uwm_stream stream) {
+  if (!p || n < 1) return fail("uwm_scale: bad argument");
+  LCHK(launch_scale(p, (size_t)n, s, (hipStream_t)stream));
+  return 0;
+}
+
+// ---- single-operator entry points
+static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }
+
+int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
+                int pad, int N, int Cout, const float* bias, float* y, double* stats, int cfg, uwm_stream stream) {
+  if (!s0 || !w || !y) return fail("uwm_op_conv: null argument");
+  ConvArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = to_src(s0); a.C0 = a.s0.C;
+  if (s1) { a.s1 = to_src(s1); a.Ctot = a.C0 + a.s1.C; } else { a.s1 = a.s0; a.Ctot = a.C0; }
+  a.Hl = a.s0.H << a.s0.up; a.Wl = a.s0.W << a.s0.up;
+  a.w = w; a.wrows = wrows; a.Kpad = Kpad; a.ntaps = kh * kw; a.kw = kw;
+  a.N = N; a.Ho = (a.Hl + 2 * pad - kh) / stride + 1; a.Wo = (a.Wl + 2 * pad - kw) / stride + 1;
+  a.Cout = Cout; a.M = N * a.Ho * a.Wo;
+  a.smul = stride; a.rmul = 1; a.off = -pad; a.sdiv = 1;
+  a.out = y; a.bias = bias;
+  if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  LCHK(launch_conv(a, (hipStream_t)stream, cfg));
+  return 0;
+}
+int uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* wd, int Cin, int KpadD, int kh, int kw,
+                 int stride, int pad, int H, int W, const float* addend, const float* mask, const float* mscale,
+                 const float* mshift, float* dx, uwm_stream stream) {
+  if (!dy || !wd || !dx) return fail("uwm_op_dgrad: null argument");
+  ConvArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = mk_src(dy, Cout, Ho, Wo); a.s1 = a.s0; a.C0 = Cout; a.Ctot = Cout;
+  a.w = wd; a.wrows = Cin; a.Kpad = KpadD; a.ntaps = kh * kw; a.kw = kw;
+  a.N = N; a.Ho = H; a.Wo = W; a.Cout = Cin; a.M = N * H * W;
+  a.Hl = Ho; a.Wl = Wo; a.smul = 1; a.rmul = -1; a.off = pad; a.sdiv = stride;
+  a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  LCHK(launch_conv(a, (hipStream_t)stream));
+  return 0;
+}
+int uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, int Ho, int Wo, int Cout, int wrows, int Kpad,
+                 int kh, int kw, int stride, int pad, float* dw, uwm_stream stream) {
+  if (!s0 || !dy || !dw) return fail("uwm_op_wgrad: null argument");
+  WgradArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = to_src(s0); a.C0 = a.s0.C;
+  if (s1) { a.s1 = to_src(s1); a.Ctot = a.C0 + a.s1.C; } else { a.s1 = a.s0; a.Ctot = a.C0; }
+  a.dy = dy; a.dw = dw; a.wrows = wrows; a.Kpad = Kpad; a.ntaps = kh * kw; a.kw = kw;
+  a.N = N; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.M = N * Ho * Wo;
+  a.Hl = a.s0.H << a.s0.up; a.Wl = a.s0.W << a.s0.up; a.stride = stride; a.pad = pad;
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  LCHK(launch_wgrad(a, (hipStream_t)stream));
+  return 0;
+}
+int uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,
+                      uwm_stream stream) {
+  if (!w || !wd) return fail("uwm_op_pack_dgrad: null argument");
+  LCHK(launch_pack_dgrad(w, Cout, Kpad, ntaps, Cin, wd, KpadD, CoutP, (hipStream_t)stream));
+  return 0;
+}
+int uwm_op_maxpool(const uwm_src* in, int N, float* out, uint8_t* idx, uwm_stream stream) {
+  if (!in || !out) return fail("uwm_op_maxpool: null argument");
+  Src s = to_src(in);
+  LCHK(launch_maxpool_fwd(s, out, idx, N, (s.H - 1) / 2 + 1, (s.W - 1) / 2 + 1, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// Weight-gradient implicit GEMM for gfx950 on v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+//   dW[co][k] = sum_m dY[m][co] * X[m][k],   m = output pixel, k = tap*Ctot + c
+//
+// The reduction dimension is the pixel index, so both operands are staged in LDS as
+// [32 pixels][tile columns] exactly as they lie in NHWC memory (columns contiguous) and the MFMA
+// fragments are read with ds_read_b32 (row stride == 16 mod 32 floats: conflict-free).
+// X is gathered with the same lazy BatchNorm+ReLU / upsample / concat transform as the forward
+// kernel; each thread's k-column (hence tap, channel, source, scale, shift) is fixed for the
+// whole pixel loop.  The pixel range is split over `nsplit` workgroups per output tile and the
+// partial tiles are combined with fp32 atomics into a pre-zeroed dW.
+//
+// Replaces the weight-gradient half of autograd's conv2d backward.
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned fdivw(unsigned n, FastDiv f) {
+  return f.d <= 1 ? n : __umulhi(n, f.mg);
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) {
+  constexpr int LA = TA + 16, LB = TB + 16;          // LDS row strides (== 16 mod 32)
+  constexpr int UA = TA / 4, RA = 256 / UA, PA = 32 / RA;
+  constexpr int UB = TB / 4, RB = 256 / UB, PB = 32 / RB;
+  constexpr int MI = TA / 2 / 16, NI = TB / 2 / 16;  // 2x2 waves
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const As = smem;                  // [2][32][LA]
+  float* const Bs = smem + 2 * 32 * LA;    // [2][32][LB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave >> 1, wb = wave & 1;
+
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const unsigned t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Kpad + TB - 1) / TB;
+  const int split = t / (tilesA * tilesB);
+  const int tt = t - split * (tilesA * tilesB);
+  const int ta = tt / tilesB, tb = tt - ta * tilesB;
+  const int a0 = ta * TA, b0 = tb * TB;
+  const int mbeg = split * a.msplit;
+  const int mend = min(a.M, mbeg + a.msplit);
+  const int nsteps = (mend - mbeg + 31) >> 5;
+
+  // ---- fixed per-thread column info
+  const int ua = tid % UA, ra = tid / UA;
+  const int ub = tid % UB, rb = tid / UB;
+  const int co = a0 + ua * 4;
+  const bool cov = co < a.Cout;
+  const unsigned kcol = b0 + ub * 4;
+  const unsigned tap = fdivw(kcol, a.dv_ctot);
+  const int c = kcol - tap * a.Ctot;
+  const unsigned r = fdivw(tap, a.dv_kw);
+  const int s = tap - r * a.kw;
+  const bool tv = (tap < (unsigned)a.ntaps) && (kcol < (unsigned)a.Kpad);
+  const bool first = c < a.C0;
+  const float* sp = first ? a.s0.ptr : a.s1.ptr;
+  const float* ssc = first ? a.s0.scale : a.s1.scale;
+  const float* ssh = first ? a.s0.shift : a.s1.shift;
+  const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
+  const int sup = first ? a.s0.up : a.s1.up;
+  const int trelu = first ? a.s0.relu : a.s1.relu;
+  const int cc = first ? c : c - a.C0;
+  const bool thas = (ssc != nullptr) && tv;
+  f4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
+  if (thas) { tsc = *(const f4*)(ssc + cc); tsh = *(const f4*)(ssh + cc); }
+  const int dh = (int)r - a.pad, dw_ = s - a.pad;
+  const int HoWo = a.Ho * a.Wo;
+
+  f4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  f4 ar[PA], br[PB];
+  unsigned bvalid = 0;
+
+  auto load_step = [&](int st) {
+    const int mb = mbeg + st * 32;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = mb + ra + RA * i;
+      const bool v = cov && m < mend;
+      ar[i] = v ? *(const f4*)(a.dy + (size_t)m * a.Cout + co) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    bvalid = 0;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int m = mb + rb + RB * i;
+      bool v = tv && m < mend;
+      const int mm = v ? m : 0;
+      const int n = mm / HoWo, rem = mm - n * HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      int hn = ho * a.stride + dh, wq = wo * a.stride + dw_;
+      v = v && hn >= 0 && hn < a.Hl && wq >= 0 && wq < a.Wl;
+      hn >>= sup; wq >>= sup;
+      const float* p = sp + ((size_t)((size_t)n * sH + hn) * sW + wq) * sC + cc;
+      br[i] = v ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
+      bvalid |= (v ? 1u : 0u) << i;
+    }
+  };
+  auto store_step = [&](int buf) {
+    float* as = As + buf * 32 * LA;
+    float* bs = Bs + buf * 32 * LB;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *(f4*)(as + (ra + RA * i) * LA + ua * 4) = ar[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      f4 v = br[i];
+      if (thas) {
+        v = v * tsc + tsh;
+        if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (!((bvalid >> i) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      }
+      *(f4*)(bs + (rb + RB * i) * LB + ub * 4) = v;
+    }
+  };
+
+  if (nsteps > 0) {
+    load_step(0);
+    store_step(0);
+  }
+  __syncthreads();
+  const int li = lane & 15, lq = lane >> 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) load_step(st + 1);
+    const float* as = As + cur * 32 * LA + wa * (TA / 2) + li;
+    const float* bs = Bs + cur * 32 * LB + wb * (TB / 2) + li;
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      float af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = as[(k4 * 4 + lq) * LA + i * 16];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = bs[(k4 * 4 + lq) * LB + j * 16];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_step(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = co][j = kcol]: lane reg e -> co = lq*4 + e, kcol = li
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int kc = b0 + wb * (TB / 2) + j * 16 + li;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = a0 + wa * (TA / 2) + i * 16 + lq * 4 + e;
+        if (row < a.wrows && kc < a.Kpad) atomicAdd(a.dw + (size_t)row * a.Kpad + kc, acc[i][j][e]);
+      }
+    }
+}
+
+template <int TA, int TB>
+static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
+  const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Kpad + TB - 1) / TB;
+  const size_t lds = (size_t)2 * 32 * (TA + 16 + TB + 16) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_igemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_igemm_kernel<TA, TB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
+  WgradArgs a = a0;
+  if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
+  const bool bigA = a.wrows > 64;
+  const int TA = bigA ? 128 : 64, TB = 128;
+  const int tiles = ((a.wrows + TA - 1) / TA) * ((a.Kpad + TB - 1) / TB);
+  // aim for ~1024 workgroups, at least 256 pixels (8 steps) per split
+  int nsplit = (1024 + tiles - 1) / tiles;
+  int maxsplit = (a.M + 255) / 256;
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  int msplit = (a.M + nsplit - 1) / nsplit;
+  msplit = (msplit + 31) & ~31;
+  nsplit = (a.M + msplit - 1) / msplit;
+  a.nsplit = nsplit; a.msplit = msplit;
+  return bigA ? launch_w<128, 128>(a, st) : launch_w<64, 128>(a, st);
+}
+
+}  // namespace uwm
