@@ -116,6 +116,12 @@ int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float l
               float eps, float weight_decay, long long step, float grad_scale, uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
 
+/* Workspace introspection for parity tests: element offset (in floats from the workspace base) and
+ * element count of a planned intermediate.  Keys: "y:<conv>", "g:<conv>" (raw conv output / its
+ * gradient; <conv> = state_dict prefix such as "encoder.layer1.0.conv1"), "xn:<i>", "gx:<i>"
+ * (encoder block i output / masked gradient), "pool", "g_pool", "x4", "dcat:<i>", "gskip:<i>". */
+int  uwm_debug_lookup(uwm_handle h, const char* key, long long* offset, long long* count);
+
 /* ---- single-operator entry points (used by the parity tests) ---- */
 typedef struct {
   const float* ptr; const float* scale; const float* shift;   /* NHWC fp32, optional lazy affine */

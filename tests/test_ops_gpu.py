@@ -195,10 +195,20 @@ def test_maxpool_ties_and_lazy_input(cuda):
     s0 = src(yd, t[0], t[1], relu=1)
     L.check(L.lib().uwm_op_maxpool(C.byref(s0), n, P(out), P(idx), stream()))
     torch.cuda.synchronize()
-    assert torch.equal(nchw(out.cpu()), ref)
-    # decode our tap index to torch's flat input index
+    got = nchw(out.cpu())
+    # the GPU contracts y*s+b into one FMA (single rounding); torch CPU rounds twice -> <= 1 ulp apart
+    assert (got - ref).abs().max() <= 4e-7 * max(1.0, float(ref.abs().max()))
+    # decode our tap index to torch's flat input index; exact ties (post-ReLU zeros) must agree,
+    # only last-ulp near-ties may pick a different tap
     tap = nchw(idx.cpu()).long()
     ho = torch.arange(h // 2).view(1, 1, -1, 1)
     wo = torch.arange(w // 2).view(1, 1, 1, -1)
     flat = (ho * 2 - 1 + tap // 3) * w + (wo * 2 - 1 + tap % 3)
-    assert torch.equal(flat, ridx)
+    diff = flat != ridx
+    assert diff.float().mean() < 1e-3
+    if diff.any():
+        af = a.flatten(2)
+        v0 = af.gather(2, flat.flatten(2))[diff.flatten(2)]
+        v1 = af.gather(2, ridx.flatten(2))[diff.flatten(2)]
+        assert (v0 - v1).abs().max() <= 4e-7 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(flat[ref == 0], ridx[ref == 0])

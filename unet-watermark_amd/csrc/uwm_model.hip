@@ -617,6 +617,63 @@ int uwm_scale(float* p, long long n, float s, uwm_stream stream) {
   return 0;
 }
 
+// ---- workspace introspection (parity tests): float offset + element count of a planned buffer.
+// keys: "y:<conv>", "g:<conv>" (<conv> = state_dict prefix, e.g. encoder.layer1.0.conv1),
+//       "xn:<i>", "gx:<i>" (encoder block i), "pool", "g_pool", "x4", "dcat:<i>", "gskip:<i>"
+int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* count) {
+  if (!h || !key || !off || !count) return fail("uwm_debug_lookup: null argument");
+  const Plan& p = h->plan;
+  if (p.N == 0) return fail("uwm_debug_lookup: no plan yet");
+  const std::string k(key);
+  const int N = p.N, H = p.H, W = p.W;
+  auto conv_geo = [&](int ci, long long* cnt) {
+    // replay the geometry walk
+    int hh = H / 2, ww = W / 2;
+    if (ci == h->stem) { *cnt = (long long)N * hh * ww * 64; return; }
+    hh /= 2; ww /= 2;
+    for (int s = 0; s < 4; ++s) for (auto& bl : h->stages[s]) {
+      const ConvL& c1 = h->convs[bl.c1]; hh /= c1.stride; ww /= c1.stride;
+      if (ci == bl.c1 || ci == bl.c2 || ci == bl.cd) { *cnt = (long long)N * hh * ww * c1.Cout; return; }
+    }
+    for (auto& d : h->dec) { hh *= 2; ww *= 2; if (ci == d.c1 || ci == d.c2) { *cnt = (long long)N * hh * ww * h->convs[d.c1].Cout; return; } }
+    *cnt = 0;
+  };
+  if (k.rfind("y:", 0) == 0 || k.rfind("g:", 0) == 0) {
+    const std::string name = k.substr(2);
+    for (size_t i = 0; i < h->convs.size(); ++i) if (h->convs[i].name == name) {
+      if ((int)i == h->head) return fail("uwm_debug_lookup: head output is the caller's logits buffer");
+      *off = (long long)(k[0] == 'y' ? p.y[i] : p.g[i]); conv_geo((int)i, count); return 0;
+    }
+    return fail("uwm_debug_lookup: unknown conv %s", name.c_str());
+  }
+  auto blk_geo = [&](size_t bi, long long* cnt) {
+    int hh = H / 4, ww = W / 4; size_t b = 0;
+    for (int s = 0; s < 4; ++s) for (auto& bl : h->stages[s]) {
+      const ConvL& c1 = h->convs[bl.c1]; hh /= c1.stride; ww /= c1.stride;
+      if (b == bi) { *cnt = (long long)N * hh * ww * c1.Cout; return; }
+      ++b;
+    }
+    *cnt = 0;
+  };
+  if (k.rfind("xn:", 0) == 0 || k.rfind("gx:", 0) == 0) {
+    const size_t bi = (size_t)atoi(k.c_str() + 3);
+    if (bi >= p.xn.size()) return fail("uwm_debug_lookup: bad block index");
+    *off = (long long)(k[0] == 'x' ? p.xn[bi] : p.gx[bi]); blk_geo(bi, count); return 0;
+  }
+  if (k == "pool" || k == "g_pool") { *off = (long long)(k == "pool" ? p.pool : p.g_pool); *count = (long long)N * (H / 4) * (W / 4) * 64; return 0; }
+  if (k == "x4") { *off = (long long)p.x4; *count = (long long)N * H * W * h->CinP; return 0; }
+  if (k.rfind("dcat:", 0) == 0 || k.rfind("gskip:", 0) == 0) {
+    const bool dc = k[0] == 'd';
+    const size_t i = (size_t)atoi(k.c_str() + (dc ? 5 : 6));
+    if (i >= h->dec.size() || p.dcat.empty()) return fail("uwm_debug_lookup: bad decoder index / eval plan");
+    const int hh = (H / 32) << (i + 1), ww = (W / 32) << (i + 1);
+    *off = (long long)(dc ? p.dcat[i] : p.gskip[i]);
+    *count = (long long)N * hh * ww * (dc ? h->dec[i].C0 + h->dec[i].C1 : h->dec[i].C1);
+    return 0;
+  }
+  return fail("uwm_debug_lookup: unknown key %s", key);
+}
+
 // ---- single-operator entry points
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }
 

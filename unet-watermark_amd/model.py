@@ -266,6 +266,12 @@ class Unet(nn.Module):
         L.check(L.lib().uwm_backward(self._h, C.c_void_p(dlogits.data_ptr()), C.c_void_p(self._ws.data_ptr()),
                                      stage_begin, stage_end, C.c_void_p(L.stream_ptr(dlogits.device))))
 
+    def debug_buffer(self, key: str) -> torch.Tensor:
+        """Flat fp32 view of a planned workspace buffer (see uwm_debug_lookup) — for parity tests."""
+        off, cnt = C.c_longlong(), C.c_longlong()
+        L.check(L.lib().uwm_debug_lookup(self._h, key.encode(), C.byref(off), C.byref(cnt)))
+        return self._ws.view(torch.float32)[off.value: off.value + cnt.value]
+
     def _logits_view(self, logits_nhwc: torch.Tensor) -> torch.Tensor:
         return logits_nhwc[..., : self.classes].permute(0, 3, 1, 2)
 

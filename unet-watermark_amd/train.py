@@ -1,0 +1,232 @@
+"""Training step of the hot path: forward -> Dice/BCE loss -> staged backward (gradient buckets
+all-reduced over RCCL while the encoder backward is still running) -> fused Adam.
+
+Counterpart of the five hot lines of /root/reference/src/train.py (:86,:91-98 / :100-105) plus the
+data-parallel exchange the reference lacks: one process per GPU, replicas of
+all parameters, per-rank BatchNorm statistics and per-rank loss — i.e. what wrapping the
+reference in DistributedDataParallel would compute — with `torch.distributed` (backend "nccl" is
+RCCL over xGMI) carrying one all-reduce per backward stage on a side HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce over a flat gradient arena.
+
+    `buckets` are [begin,end) element ranges (model.stages: head+decoder, layer4, layer3, layer2,
+    layer1+stem — the order backward completes them).  reduce(k) enqueues the SUM all-reduce of
+    bucket k on a side stream gated by an event recorded on the compute stream; finish() makes the
+    compute stream wait for all of them.  Averaging (1/world) is folded into the optimizer's
+    grad_scale.  Works on CPU tensors with the gloo backend (tests) — then without streams.
+    """
+
+    def __init__(self, flat_grads: torch.Tensor, buckets: Sequence[Tuple[int, int]], group=None):
+        self.flat = flat_grads
+        self.buckets = [(int(b), int(e)) for b, e in buckets if e > b]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.on_gpu = flat_grads.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if (self.on_gpu and self.world > 1) else None
+        self._works = []
+
+    def reduce(self, k: int):
+        if self.world == 1:
+            return
+        b, e = self.buckets[k]
+        view = self.flat[b:e]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._works:
+            w.wait()                       # GPU: current stream waits on the collective's stream
+        self._works.clear()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+
+
+def broadcast_model(model, src: int = 0, group=None):
+    """Rank `src`'s parameters and BatchNorm buffers to every rank (DDP's initial sync)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    dist.broadcast(model.flat_parameters(), src=src, group=group)
+    dist.broadcast(model._buffer_arena, src=src, group=group)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (coupled L2) as ONE kernel launch
+    over the model's flat parameter arena (/root/reference/src/train.py:266-270 builds optim.Adam)."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._m = None
+        self._v = None
+        self._step = 0
+
+    def _state_init(self):
+        p = self.model.flat_parameters()
+        if self._m is None or self._m.device != p.device:
+            self._m = torch.zeros_like(p)
+            self._v = torch.zeros_like(p)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self._state_init()
+        self._step += 1
+        p = self.model.flat_parameters()
+        gr = self.model.flat_grads()
+        L.check(L.lib().uwm_adam(C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._m.data_ptr()),
+                                 C.c_void_p(self._v.data_ptr()), p.numel(), float(g["lr"]), float(g["betas"][0]),
+                                 float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step,
+                                 float(grad_scale), C.c_void_p(L.stream_ptr(p.device))))
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        # gradients live in the flat arena and are overwritten (not accumulated) by every backward
+        for p in self.model.parameters():
+            p.grad = None
+
+    def state_dict(self):
+        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._step = int(sd["step"])
+        self._state_init()
+        if sd.get("exp_avg") is not None:
+            self._m.copy_(sd["exp_avg"]); self._v.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update(s)
+
+
+class Trainer:
+    """The fused train step used by bench.py and the CLI: no autograd graph, no per-parameter
+    Python work; same arithmetic as `model(x); criterion(...); loss.backward(); optimizer.step()`."""
+
+    def __init__(self, model, w_dice: float = 1.0, w_bce: float = 0.0, smooth: float = 1e-5, eps: float = 1e-7,
+                 lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0,
+                 group=None, overlap_comm: bool = True):
+        self.model = model
+        self.w_dice, self.w_bce, self.smooth, self.eps = float(w_dice), float(w_bce), float(smooth), float(eps)
+        self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.overlap = overlap_comm
+        self._reducer = None
+        self._dl = None
+        self._scratch = None
+        self._loss = None
+        if self.world > 1:
+            broadcast_model(model, 0, group)
+
+    def _buffers(self, n, h, w, dev):
+        cp = self.model._cp
+        if self._dl is None or self._dl.shape != (n, h, w, cp) or self._dl.device != dev:
+            self._dl = torch.empty((n, h, w, cp), dtype=torch.float32, device=dev)
+            self._scratch = torch.empty(8, dtype=torch.float64, device=dev)
+            self._loss = torch.empty(3, dtype=torch.float32, device=dev)
+
+    def step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+        """images (N,C,H,W) fp32, masks (N,H,W)|(N,1,H,W) int64|uint8|float32 on the HIP device.
+        Returns a device tensor {total, dice, bce} (no host sync)."""
+        m = self.model
+        if not m.training:
+            m.train()
+        n, _, h, w = images.shape
+        dev = images.device
+        logits = m._forward_raw(images, training=True)
+        self._buffers(n, h, w, dev)
+        t = masks.contiguous()
+        if t.numel() != n * h * w:
+            raise ValueError(f"masks have {t.numel()} elements, expected {n * h * w}")
+        st = C.c_void_p(L.stream_ptr(dev))
+        L.check(L.lib().uwm_loss(C.c_void_p(logits.data_ptr()), m._cp, C.c_void_p(t.data_ptr()), L.target_dtype_code(t),
+                                 n * h * w, self.w_dice, self.w_bce, self.smooth, self.eps,
+                                 C.c_void_p(self._scratch.data_ptr()), C.c_void_p(self._loss.data_ptr()),
+                                 C.c_void_p(self._dl.data_ptr()), m._cp, 1.0, st))
+        nst = len(m.stages)
+        if self.world > 1:
+            if self._reducer is None or self._reducer.flat.data_ptr() != m.flat_grads().data_ptr():
+                self._reducer = GradReducer(m.flat_grads(), m.stages, self.group)
+            if self.overlap:
+                for k in range(nst):
+                    m._backward_raw(self._dl, k, k + 1)
+                    self._reducer.reduce(k)
+            else:
+                m._backward_raw(self._dl, 0, nst)
+                for k in range(nst):
+                    self._reducer.reduce(k)
+            self._reducer.finish()
+        else:
+            m._backward_raw(self._dl, 0, nst)
+        self.opt.step(grad_scale=1.0 / self.world)
+        return self._loss
+
+
+# ------------------------------------------------------------------------------------ loops
+def train_epoch(model, train_loader, criterion, optimizer, device, metrics=None, log_interval: int = 10):
+    """Counterpart of train_epoch (/root/reference/src/train.py:68-127) in the reference's own call
+    order (model -> criterion -> backward -> optimizer.step); fp32 throughout (no GradScaler)."""
+    from .metrics import logits_metrics
+    model.train()
+    total = torch.zeros((), device=device)
+    nb = 0
+    mvals = {k: 0.0 for k in ("iou", "f1", "accuracy", "recall", "precision")}
+    interval = max(1, len(train_loader) // 10)
+    for i, (images, masks) in enumerate(train_loader):
+        images = images.to(device, non_blocking=True)
+        masks = masks.to(device, non_blocking=True)
+        optimizer.zero_grad()
+        outputs = model(images)
+        if masks.dim() == 3:
+            masks = masks.unsqueeze(1)
+        loss = criterion(outputs, masks)
+        loss.backward()
+        optimizer.step()
+        total += loss.detach()
+        nb += 1
+        if i % interval == 0:
+            for k, v in logits_metrics(outputs.detach(), masks).items():
+                mvals[k] += v
+    nb = max(nb, 1)
+    ncalc = max(1, (nb + interval - 1) // interval)
+    return float(total) / nb, {k: v / ncalc for k, v in mvals.items()}
+
+
+@torch.no_grad()
+def validate(model, val_loader, criterion, device):
+    """Counterpart of validate (/root/reference/src/train.py:129-173)."""
+    from .metrics import logits_metrics
+    model.eval()
+    total = torch.zeros((), device=device)
+    nb = 0
+    mvals = {k: 0.0 for k in ("iou", "f1", "accuracy", "recall", "precision")}
+    for images, masks in val_loader:
+        images = images.to(device, non_blocking=True)
+        masks = masks.to(device, non_blocking=True)
+        outputs = model(images)
+        if masks.dim() == 3:
+            masks = masks.unsqueeze(1)
+        total += criterion(outputs, masks)
+        nb += 1
+        for k, v in logits_metrics(outputs, masks).items():
+            mvals[k] += v
+    nb = max(nb, 1)
+    return float(total) / nb, {k: v / nb for k, v in mvals.items()}
