@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): train images/s of Unet(resnet34) at 512x512, batch 16 per GPU,
+one process per GPU (torch.distributed over RCCL), synthetic data resident in HBM.
+
+A "step" = zero_grad + forward + Dice loss + backward + (bucketed gradient all-reduce) + Adam — the
+hot lines of /root/reference/src/train.py:86-105 — on configs[1] of BASELINE.json.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded around every
+conv / wgrad launch on the compute stream during the timed region (uwm_prof_*); `cpu_baseline` times
+the CPU oracle (the reference's CPU path restated in plain torch) on this host's cores on a bounded
+sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
+
+
+def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0):
+    """Oracle (torch CPU fp32) train step on a bounded sample: bs2 at the bench resolution."""
+    import torch
+    from oracle import unet_oracle as O
+    cores = len(os.sched_getaffinity(0))
+    try:                                     # cgroup CPU quota (the GPU box shows 256 cores but grants 16)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    cores = torch.get_num_threads()
+    bs = 2
+    model = O.build(encoder, seed=42)
+    model.train()
+    crit = O.DiceLoss(smooth=1e-5)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    x, t = O.synthetic_batch(bs, hw, hw, seed=42)
+    O.train_step(model, crit, opt, x, t)                      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < budget_s / 2 and n < 8):
+        O.train_step(model, crit, opt, x, t)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"Unet-{encoder} {hw}x{hw} bs{bs} fwd+Dice+bwd+Adam on torch-CPU fp32 oracle, 1 warm-up + {n} timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--encoder", default="resnet34")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import unet_watermark_amd as U
+    from unet_watermark_amd import _lib as L
+    from unet_watermark_amd.train import Trainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    torch.manual_seed(42)                                  # identical init on every rank (+ broadcast in Trainer)
+    model = U.Unet(args.encoder, encoder_weights=None, in_channels=3, classes=1).to(dev)
+    trainer = Trainer(model, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-4, weight_decay=1e-4,
+                      overlap_comm=not args.no_overlap)
+    g = torch.Generator(device="cpu").manual_seed(42 + rank)      # rank-distinct synthetic data
+    n, s = args.batch, args.size
+    x = torch.randn(n, 3, s, s, generator=g).to(dev)
+    t = torch.zeros(n, s, s, dtype=torch.int64)
+    for i in range(n):                                             # seeded rectangles, 5-20 % area
+        frac = 0.05 + 0.15 * float(torch.rand((), generator=g))
+        rh = max(1, int((frac * s * s) ** 0.5)); rw = max(1, min(s, int(frac * s * s / rh)))
+        y0 = int(torch.randint(0, s - rh + 1, (), generator=g)); x0 = int(torch.randint(0, s - rw + 1, (), generator=g))
+        t[i, y0:y0 + rh, x0:x0 + rw] = 1
+    t = t.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        loss = trainer.step(x, t)
+    barrier()
+    L.lib().uwm_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(x, t)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.lib().uwm_prof_enable(0)
+    prof = (C.c_double * (16 * 3))()
+    ncls = L.lib().uwm_prof_collect(prof, 16)
+    loss_val = float(loss[0].item())
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        from oracle.unet_oracle import conv_flops
+        fwd, fwdbwd = conv_flops(args.encoder, s, s)
+        kernels = []
+        tot_ms = tot_fl = 0.0
+        for c in range(ncls):
+            cnt, ms, fl = prof[c * 3], prof[c * 3 + 1], prof[c * 3 + 2]
+            if cnt > 0:
+                kernels.append({"kernel": L.lib().uwm_prof_class_name(c).decode(), "launches_per_step": cnt / args.steps,
+                                "avg_us": round(1e3 * ms / cnt, 2), "ms_per_step": round(ms / args.steps, 3),
+                                "tflops": round(fl / ms / 1e9, 2)})
+                tot_ms += ms; tot_fl += fl
+        kernels.sort(key=lambda k: -k["ms_per_step"])
+        dom = kernels[0] if kernels else None
+        ms_step = 1e3 * dt / args.steps
+        out = {
+            "metric": "train_images_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Unet-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
+                                   f"(BASELINE.json configs[{1 if world == 1 else 2}])",
+                       "global_batch": world * n, "image": [s, s], "parallelism": f"dp{world}",
+                       "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if world > 1 else "none")},
+            "loss": round(loss_val, 6),
+            "model_tflops": round(world * n * fwdbwd * args.steps / dt / 1e12, 2),
+            "roofline": None, "kernels": kernels,
+        }
+        if dom:
+            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                               "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(dom["tflops"] / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_launch_us": dom["avg_us"],
+                               "all_conv_kernels": {"tflops": round(tot_fl / tot_ms / 1e9, 2),
+                                                    "frac": round(tot_fl / tot_ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                                    "share_of_step": round(tot_ms / args.steps / ms_step, 4)}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.encoder, s)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@
  *   - activations are NHWC fp32 with channels padded to a multiple of 4; logits are returned as
  *     [N][H][W][CP], CP = uwm_logits_channels() (class k at channel k).
  *   - parameters live in ONE flat fp32 arena (caller-owned) whose layout the library defines:
- *     uwm_tensor_info() gives, per smp-compatible state_dict key, the arena offset plus logical
+ *     uwm_tensor_info_get() gives, per smp-compatible state_dict key, the arena offset plus logical
  *     OIHW shape and element strides (convolution weights are stored [O][kh][kw][I] with each
  *     output-channel row padded to a multiple of 32 floats).  Gradients use the same layout in a
  *     second arena; BatchNorm running statistics live in a third ("buffer") arena.
@@ -115,6 +115,13 @@ int  uwm_threshold(const float* logits, int ld, long long npix, float threshold,
 int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
               float eps, float weight_decay, long long step, float grad_scale, uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
+
+/* Optional HIP-event profiler: while enabled every conv / wgrad launch is bracketed by a hipEvent pair
+ * recorded on its launch stream.  uwm_prof_collect waits for the events and returns, per kernel class,
+ * {launches, total ms, total algorithmic FLOPs} in out[class*3 + 0..2]; returns the number of classes. */
+int  uwm_prof_enable(int on);
+int  uwm_prof_collect(double* out, int max_classes);
+const char* uwm_prof_class_name(int cls);
 
 /* Workspace introspection for parity tests: element offset (in floats from the workspace base) and
  * element count of a planned intermediate.  Keys: "y:<conv>", "g:<conv>" (raw conv output / its

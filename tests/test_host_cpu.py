@@ -1,0 +1,108 @@
+"""CPU tests of the host layer: the C-ABI library loads and exports every symbol include/uwm.h declares,
+the parameter arena / state_dict contract, constructor validation, and loud failure without a GPU.
+No compute call is made here (there is no GPU in this container)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def U():
+    import __graft_entry__ as g
+    g.build()
+    import unet_watermark_amd as U
+    return U
+
+
+def test_abi_exports_every_declared_symbol(U):
+    from unet_watermark_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "uwm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # declarations only, not prose
+    declared = set(re.findall(r"\b(uwm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"uwm_model"}
+    lib = L.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/uwm.h but not exported by libuwm.so"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    assert lib.uwm_version() >= 1
+
+
+def test_state_dict_contract_matches_oracle(U):
+    from oracle import unet_oracle as O
+    for enc, count in (("resnet18", 14_328_209), ("resnet34", 24_436_369)):
+        m, ref = U.Unet(enc), O.build(enc)
+        sd, so = m.state_dict(), ref.state_dict()
+        assert list(sd.keys()) == list(so.keys())
+        assert all(sd[k].shape == so[k].shape and sd[k].dtype == so[k].dtype for k in so)
+        assert m.num_parameters() == count == sum(p.numel() for p in m.parameters())
+        m.load_state_dict(so)
+        assert all(torch.equal(m.state_dict()[k], so[k]) for k in so)
+        # padding of the arena stays exactly zero: sum over the arena == sum over the logical tensors
+        logical = sum(float(v.double().abs().sum()) for k, v in so.items() if v.dtype.is_floating_point and "running" not in k)
+        assert abs(float(m.flat_parameters().double().abs().sum()) - logical) < 1e-6 * logical
+        # stage (gradient bucket) ranges tile the arena
+        assert m.stages[0][0] == 0 and m.stages[-1][1] == m.flat_parameters().numel()
+        assert all(m.stages[i][1] == m.stages[i + 1][0] for i in range(len(m.stages) - 1))
+
+
+def test_init_follows_smp_spec(U):
+    torch.manual_seed(0)
+    m = U.Unet("resnet18")
+    sd = m.state_dict()
+    w = sd["encoder.layer1.0.conv1.weight"]               # kaiming_normal fan_out: std = sqrt(2/(64*9))
+    assert abs(float(w.std()) - (2.0 / (64 * 9)) ** 0.5) < 0.1 * (2.0 / (64 * 9)) ** 0.5
+    wd = sd["decoder.blocks.0.conv1.0.weight"]            # kaiming_uniform fan_in: bound = sqrt(6/fan_in)
+    assert float(wd.abs().max()) <= (6.0 / (768 * 9)) ** 0.5 + 1e-6
+    assert float(sd["segmentation_head.0.bias"].abs().sum()) == 0.0
+    assert torch.all(sd["encoder.bn1.weight"] == 1) and torch.all(sd["encoder.bn1.running_var"] == 1)
+    assert int(sd["encoder.bn1.num_batches_tracked"]) == 0
+
+
+def test_constructor_rejects_unsupported(U):
+    for kw in (dict(encoder_name="efficientnet-b4"), dict(encoder_weights="imagenet"), dict(decoder_attention_type="scse"),
+               dict(activation="sigmoid"), dict(aux_params={"classes": 2}), dict(decoder_channels=(256, 128, 64)),
+               dict(encoder_depth=4, decoder_channels=(256, 128, 64, 32)), dict(decoder_channels=(256, 128, 64, 32, 10))):
+        with pytest.raises(ValueError):
+            U.Unet(**kw)
+    with pytest.raises(ValueError, match="Unsupported model"):
+        U.create_model("UnetPlusPlus")
+
+
+def test_config_factories(U):
+    class NS:
+        def __init__(self, **kw): self.__dict__.update(kw)
+    cfg = NS(MODEL=NS(NAME="Unet", ENCODER_NAME="resnet18", ENCODER_WEIGHTS=None, IN_CHANNELS=3, CLASSES=1, ACTIVATION=None,
+                      ENCODER_DEPTH=5, DECODER_CHANNELS=[256, 128, 64, 32, 16]),
+             LOSS=NS(NAME="DiceLoss", MODE="binary", SMOOTH=1e-5, BCE_WEIGHT=0.5, DICE_WEIGHT=0.5))
+    assert isinstance(U.create_model_from_config(cfg), U.Unet)
+    assert isinstance(U.get_loss_function(cfg), U.DiceLoss)
+    cfg.LOSS.NAME = "CombinedLoss"
+    assert isinstance(U.get_loss_function(cfg), U.CombinedLoss)
+    cfg.LOSS.NAME = "LovaszLoss"
+    with pytest.raises(ValueError):
+        U.get_loss_function(cfg)
+
+
+def test_no_cpu_fallback(U):
+    m = U.Unet("resnet18")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        U.DiceLoss()(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        U.get_metrics()(torch.zeros(1, 8, 8), torch.zeros(1, 8, 8, dtype=torch.long))
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the product package may import or execute it."""
+    pkg = os.path.join(ROOT, "unet-watermark_amd")
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|from\s+\.+oracle)|oracle\.|unet_oracle", re.M)
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not pat.search(src), f"{f} references the oracle"

@@ -1,0 +1,115 @@
+"""CPU tests of the oracle (test infrastructure): self-checks that stand in for the upstream tests the
+reference lacks + the committed golden vectors that pin the oracle itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_parameter_counts_and_state_dict_keys():
+    m34, m18 = O.build("resnet34"), O.build("resnet18")
+    assert sum(p.numel() for p in m34.parameters()) == 24_436_369
+    assert sum(p.numel() for p in m18.parameters()) == 14_328_209
+    keys = list(m34.state_dict().keys())
+    assert keys[0] == "encoder.conv1.weight" and keys[-1] == "segmentation_head.0.bias"
+    for k in ("encoder.bn1.num_batches_tracked", "encoder.layer2.0.downsample.0.weight", "encoder.layer4.2.conv2.weight",
+              "decoder.blocks.0.conv1.0.weight", "decoder.blocks.4.conv2.1.running_var", "segmentation_head.0.weight"):
+        assert k in keys, k
+    sd = m34.state_dict()
+    assert sd["decoder.blocks.0.conv1.0.weight"].shape == (256, 768, 3, 3)
+    assert sd["decoder.blocks.4.conv1.0.weight"].shape == (16, 32, 3, 3)
+    assert sd["segmentation_head.0.weight"].shape == (1, 16, 3, 3)
+    assert not any(k.startswith("encoder.fc") for k in keys)
+
+
+def test_conv_flops_match_survey():
+    assert O.conv_flops("resnet34", 512, 512) == (62_511_906_816, 186_302_595_072)
+    assert O.conv_flops("resnet18", 256, 256) == (10_796_138_496, 32_080_134_144)
+
+
+def test_input_shape_check():
+    m = O.build("resnet18")
+    with pytest.raises(RuntimeError, match="divisible by 32"):
+        m(torch.zeros(1, 3, 100, 64))
+
+
+def test_dice_closed_forms():
+    dice = O.DiceLoss(smooth=0.0)
+    big = 40.0
+    x = torch.tensor([[[[big, big], [-big, -big]]]])
+    t = torch.tensor([[[[1, 0], [1, 0]]]])
+    assert abs(float(dice(x, t)) - 0.5) < 1e-6                 # I=1, sum p=2, sum t=2
+    assert abs(float(dice(x, torch.tensor([[[[1, 1], [0, 0]]]])))) < 1e-6        # perfect overlap
+    # all-negative batch => loss 0 and zero gradient
+    xr = torch.randn(2, 1, 8, 8, requires_grad=True)
+    l = O.DiceLoss(smooth=1e-5)(xr, torch.zeros(2, 1, 8, 8, dtype=torch.long))
+    l.backward()
+    assert float(l) == 0.0 and float(xr.grad.abs().max()) == 0.0
+    # the reduction spans batch AND pixels (one Dice for the whole batch)
+    x2 = torch.randn(2, 1, 4, 4); t2 = (torch.rand(2, 1, 4, 4) > 0.5).long()
+    p = torch.sigmoid(x2)
+    exp = 1 - (2 * (p * t2).sum() + 1e-5) / ((p + t2).sum() + 1e-5)
+    assert abs(float(O.DiceLoss(smooth=1e-5)(x2, t2)) - float(exp)) < 1e-6
+
+
+def test_metrics_closed_forms():
+    out = torch.tensor([[[0.9, 0.2], [0.6, 0.5]]])            # >= 0.5 -> [[1,0],[1,1]]
+    tgt = torch.tensor([[[1, 0], [0, 1]]])
+    tp, fp, fn, tn = O.get_stats(out, tgt)
+    assert (int(tp), int(fp), int(fn), int(tn)) == (2, 1, 0, 1)
+    m = O.micro_metrics(tp, fp, fn, tn)
+    assert abs(m["iou"] - 2 / 3) < 1e-12 and abs(m["precision"] - 2 / 3) < 1e-12 and m["recall"] == 1.0
+    z = O.compute_metrics(torch.zeros(1, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+    assert z["iou"] == 1.0 and z["f1"] == 1.0               # zero_division = 1.0
+    # predict.py thresholds RAW logits (no sigmoid)
+    lg = torch.tensor([[[[0.4, 0.6], [-1.0, 2.0]]]])
+    assert O.predict_mask(lg, 0.5).flatten().tolist() == [0, 255, 0, 255]
+    assert O.predict_mask(lg, 0.5, apply_sigmoid=True).flatten().tolist() == [255, 255, 0, 255]
+
+
+@pytest.mark.parametrize("name", ["unet_r18_256", "unet_r18_64_combo", "unet_r34_64"])
+def test_oracle_reproduces_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    enc, n, h, w, seed, loss = str(g["encoder"]), int(g["n"]), int(g["h"]), int(g["w"]), int(g["seed"]), str(g["loss"])
+    model = O.build(enc, seed=seed)
+    model.train()
+    x, t = O.synthetic_batch(n, h, w, seed=seed)
+    out = model(x)
+    assert out.shape == (n, 1, h, w)
+    assert int(g["n_params"]) == sum(p.numel() for p in model.parameters())
+    assert int(t.sum()) == int(g["target_sum"])
+    # summation order inside oneDNN may change with the thread count: fp32-noise tolerances
+    assert np.allclose(out.detach()[:, :, :32, :32].numpy(), g["logits_crop"], atol=2e-4)
+    assert abs(float(out.double().sum()) - float(g["logits_sum"])) < 1e-3 * float(g["logits_abs_sum"])
+    dice = O.DiceLoss(smooth=1e-5)(out, t.unsqueeze(1)); bce = O.BCEWithLogits()(out, t.unsqueeze(1))
+    assert abs(float(dice) - float(g["loss_dice"])) < 1e-5 and abs(float(bce) - float(g["loss_bce"])) < 1e-5
+    l = dice if loss == "dice" else 0.5 * bce + 0.5 * dice
+    l.backward()
+    gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    assert np.allclose(gn, g["grad_norm"], rtol=3e-2, atol=1e-7)
+    assert [k for k, _ in model.named_parameters()] == list(g["param_names"])
+
+
+def test_kernel_vectors():
+    g = np.load(os.path.join(GOLD, "kernels.npz"))
+    y = torch.nn.functional.conv2d(torch.from_numpy(g["conv_x"]), torch.from_numpy(g["conv_w"]), None, 1, 1)
+    assert np.allclose(y.numpy(), g["conv_y"], atol=1e-5)
+    lg = torch.from_numpy(g["loss_logits"]).requires_grad_(); tg = torch.from_numpy(g["loss_target"])
+    dice, bce = O.DiceLoss(smooth=1e-5)(lg, tg), O.BCEWithLogits()(lg, tg)
+    assert abs(float(dice) - float(g["loss_dice"])) < 1e-6 and abs(float(bce) - float(g["loss_bce"])) < 1e-6
+    (0.5 * dice + 0.5 * bce).backward()
+    assert np.allclose(lg.grad.numpy(), g["loss_grad"], atol=1e-8)
+    # BatchNorm train: biased variance normalises, UNBIASED variance goes to running_var
+    x = torch.from_numpy(g["bn_x"]).double()
+    mu, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
+    yy = (x - mu[None, :, None, None]) / torch.sqrt(var + 1e-5)[None, :, None, None] * torch.from_numpy(g["bn_gamma"]).double()[None, :, None, None] \
+        + torch.from_numpy(g["bn_beta"]).double()[None, :, None, None]
+    assert np.allclose(yy.numpy(), g["bn_y"], atol=1e-5)
+    cnt = x.numel() / x.shape[1]
+    assert np.allclose(0.9 * 1.0 + 0.1 * (var * cnt / (cnt - 1)).numpy(), g["bn_running_var"], atol=1e-5)
+    assert np.allclose(0.1 * mu.numpy(), g["bn_running_mean"], atol=1e-6)

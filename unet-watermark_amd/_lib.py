@@ -61,6 +61,9 @@ SIGNATURES = {
     "uwm_threshold": (I, [P, I, L, F, I, P, P]),
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
     "uwm_scale": (I, [P, L, F, P]),
+    "uwm_prof_enable": (I, [I]),
+    "uwm_prof_collect": (I, [C.POINTER(C.c_double), I]),
+    "uwm_prof_class_name": (C.c_char_p, [I]),
     "uwm_debug_lookup": (I, [P, C.c_char_p, C.POINTER(L), C.POINTER(L)]),
     "uwm_op_conv": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, P, P, P, I, P]),
     "uwm_op_dgrad": (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P]),

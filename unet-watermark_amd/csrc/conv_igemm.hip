@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st) {
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
   static bool attr_set = false;
@@ -244,7 +244,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  if (prof_on()) prof_begin(cls, a.flops, st);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
+  if (prof_on()) prof_end(st);
   return hipGetLastError();
 }
 
@@ -265,12 +267,12 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
     }
   }
   switch (cfg) {
-    case 0: return launch_cfg<128, 128, 2, 2>(a, st);
-    case 1: return launch_cfg<128, 64, 2, 2>(a, st);
-    case 2: return launch_cfg<128, 32, 4, 1>(a, st);
-    case 3: return launch_cfg<128, 16, 4, 1>(a, st);
-    case 4: return launch_cfg<64, 64, 2, 2>(a, st);
-    case 5: return launch_cfg<64, 128, 1, 4>(a, st);
+    case 0: return launch_cfg<128, 128, 2, 2>(a, st, 0);
+    case 1: return launch_cfg<128, 64, 2, 2>(a, st, 1);
+    case 2: return launch_cfg<128, 32, 4, 1>(a, st, 2);
+    case 3: return launch_cfg<128, 16, 4, 1>(a, st, 3);
+    case 4: return launch_cfg<64, 64, 2, 2>(a, st, 4);
+    case 5: return launch_cfg<64, 128, 1, 4>(a, st, 5);
     default: return hipErrorInvalidValue;
   }
 }

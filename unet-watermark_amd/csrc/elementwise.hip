@@ -4,6 +4,7 @@
 // Reference semantics replaced: torch BatchNorm2d / ReLU / MaxPool2d / interpolate+cat autograd
 // and optim.Adam as driven by /root/reference/src/train.py:96-105 (SURVEY.md §8 a4,a9,a10,a14,a15).
 #include "uwm_kernels.h"
+#include <vector>
 
 namespace uwm {
 
@@ -390,6 +391,46 @@ __global__ void scale_kernel(float* __restrict__ p, size_t n, float s) {
 hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st) {
   hipLaunchKernelGGL(scale_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, p, n, s);
   return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ HIP-event profiler (host side)
+struct ProfRec { int cls; double flops; hipEvent_t e0, e1; };
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void prof_enable(bool on) { g_prof = on; }
+bool prof_on() { return g_prof; }
+void prof_begin(int cls, double flops, hipStream_t st) {
+  ProfRec r; r.cls = cls; r.flops = flops; r.e0 = prof_event(); r.e1 = prof_event();
+  (void)hipEventRecord(r.e0, st);
+  g_recs.push_back(r);
+}
+void prof_end(hipStream_t st) { if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, st); }
+int prof_collect(double* out) {
+  for (int i = 0; i < kProfClasses * 3; ++i) out[i] = 0.0;
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.cls >= 0 && r.cls < kProfClasses) {
+      out[r.cls * 3 + 0] += 1.0; out[r.cls * 3 + 1] += (double)ms; out[r.cls * 3 + 2] += r.flops;
+    }
+    g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+  }
+  const int n = (int)g_recs.size();
+  g_recs.clear();
+  return n;
+}
+const char* prof_class_name(int cls) {
+  static const char* names[kProfClasses] = {
+      "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,2,2>", "conv_igemm_kernel<128,32,4,1>",
+      "conv_igemm_kernel<128,16,4,1>",  "conv_igemm_kernel<64,64,2,2>",  "conv_igemm_kernel<64,128,1,4>",
+      "wgrad_igemm_kernel<64,128,2,2>", "wgrad_igemm_kernel<128,128,2,2>", "wgrad_igemm_kernel<16,256,1,4>",
+      "wgrad_igemm_kernel<32,256,1,4>"};
+  return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 
 }  // namespace uwm

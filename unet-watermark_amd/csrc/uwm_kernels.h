@@ -42,6 +42,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   const float* mscale; const float* mshift;
   double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
   FastDiv dv_ctot, dv_kw;
+  double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
 };
 
 struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = tap*Ctot + c)
@@ -53,7 +54,18 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   int Hl, Wl, stride, pad;
   int nsplit, msplit;        // pixel range per split (multiple of 32)
   FastDiv dv_ctot, dv_kw;
+  double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
 };
+
+// ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
+// the launch stream; classes 0..5 = conv tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256
+enum { kProfClasses = 10 };
+void prof_enable(bool on);
+bool prof_on();
+void prof_begin(int cls, double flops, hipStream_t st);
+void prof_end(hipStream_t st);
+int  prof_collect(double* out /* [kProfClasses][3] = launches, ms, flops */);
+const char* prof_class_name(int cls);
 
 // ---- launchers (all asynchronous on `st`, no host sync, no allocation) ----
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg = -1);

@@ -285,6 +285,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   a.out = out; a.bias = cv.bias_off >= 0 ? c.m->params + cv.bias_off : nullptr;
   if (stats && cv.bn >= 0) { const BNL& b = c.m->bns[cv.bn]; a.ssum = c.D(b.d_off); a.ssq = c.D(b.d_off) + b.C; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
   return launch_conv(a, c.st, cfg);
 }
 
@@ -299,6 +300,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.Hl = Ho; a.Wl = Wo; a.smul = 1; a.rmul = -1; a.off = cv.pad; a.sdiv = cv.stride;
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
   return launch_conv(a, c.st);
 }
 
@@ -311,6 +313,7 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.N = c.N; a.Ho = Ho; a.Wo = Wo; a.Cout = cv.CoutP; a.M = c.N * Ho * Wo;
   a.Hl = s0.H << s0.up; a.Wl = s0.W << s0.up; a.stride = cv.stride; a.pad = cv.pad;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
   return launch_wgrad(a, c.st);
 }
 
@@ -616,6 +619,14 @@ int uwm_scale(float* p, long long n, float s, uwm_stream stream) {
   LCHK(launch_scale(p, (size_t)n, s, (hipStream_t)stream));
   return 0;
 }
+
+// ---- HIP-event profiler (bench.py's roofline leg)
+int uwm_prof_enable(int on) { prof_enable(on != 0); return 0; }
+int uwm_prof_collect(double* out, int max_classes) {
+  if (!out || max_classes < kProfClasses) return fail("uwm_prof_collect: need room for %d classes", (int)kProfClasses);
+  prof_collect(out); return kProfClasses;
+}
+const char* uwm_prof_class_name(int cls) { return prof_class_name(cls); }
 
 // ---- workspace introspection (parity tests): float offset + element count of a planned buffer.
 // keys: "y:<conv>", "g:<conv>" (<conv> = state_dict prefix, e.g. encoder.layer1.0.conv1),

@@ -21,18 +21,20 @@ __device__ __forceinline__ unsigned fdivw(unsigned n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.mg);
 }
 
-template <int TA, int TB>
+template <int TA, int TB, int WA, int WB>
 __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) {
   constexpr int LA = TA + 16, LB = TB + 16;          // LDS row strides (== 16 mod 32)
-  constexpr int UA = TA / 4, RA = 256 / UA, PA = 32 / RA;
-  constexpr int UB = TB / 4, RB = 256 / UB, PB = 32 / RB;
-  constexpr int MI = TA / 2 / 16, NI = TB / 2 / 16;  // 2x2 waves
+  constexpr int UA = TA / 4, RA = (256 / UA) > 32 ? 32 : (256 / UA), PA = 32 / RA;
+  constexpr int UB = TB / 4, RB = (256 / UB) > 32 ? 32 : (256 / UB), PB = 32 / RB;
+  constexpr int MI = TA / WA / 16, NI = TB / WB / 16;
+  static_assert(WA * WB == 4 && MI >= 1 && NI >= 1, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;                  // [2][32][LA]
   float* const Bs = smem + 2 * 32 * LA;    // [2][32][LB]
+  int* const Rw = (int*)(Bs + 2 * 32 * LB);   // [2][32][4]: per pixel row {n, ho*stride-pad, wo*stride-pad, valid}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wa = wave >> 1, wb = wave & 1;
+  const int wa = wave / WB, wb = wave % WB;
 
   const unsigned nblk = gridDim.x, bid = blockIdx.x;
   const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
@@ -48,15 +50,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
 
   // ---- fixed per-thread column info
   const int ua = tid % UA, ra = tid / UA;
+  const bool a_act = tid < UA * RA;
   const int ub = tid % UB, rb = tid / UB;
+  const bool b_act = tid < UB * RB;
   const int co = a0 + ua * 4;
-  const bool cov = co < a.Cout;
+  const bool cov = a_act && co < a.Cout;
   const unsigned kcol = b0 + ub * 4;
   const unsigned tap = fdivw(kcol, a.dv_ctot);
   const int c = kcol - tap * a.Ctot;
   const unsigned r = fdivw(tap, a.dv_kw);
   const int s = tap - r * a.kw;
-  const bool tv = (tap < (unsigned)a.ntaps) && (kcol < (unsigned)a.Kpad);
+  const bool tv = b_act && (tap < (unsigned)a.ntaps) && (kcol < (unsigned)a.Kpad);
   const bool first = c < a.C0;
   const float* sp = first ? a.s0.ptr : a.s1.ptr;
   const float* ssc = first ? a.s0.scale : a.s1.scale;
@@ -68,7 +72,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   const bool thas = (ssc != nullptr) && tv;
   f4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
   if (thas) { tsc = *(const f4*)(ssc + cc); tsh = *(const f4*)(ssh + cc); }
-  const int dh = (int)r - a.pad, dw_ = s - a.pad;
   const int HoWo = a.Ho * a.Wo;
 
   f4 acc[MI][NI];
@@ -80,6 +83,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   f4 ar[PA], br[PB];
   unsigned bvalid = 0;
 
+  // one thread per pixel row decomposes m -> (n, ho, wo) for a whole step; everyone else reads LDS
+  auto row_info = [&](int st) {
+    if (tid < 32) {
+      const int m = mbeg + st * 32 + tid;
+      const bool v = m < mend;
+      const int mm = v ? m : 0;
+      const int n = mm / HoWo, rem = mm - n * HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      int4 ri = make_int4(n, ho * a.stride - a.pad, wo * a.stride - a.pad, v ? 1 : 0);
+      *(int4*)(Rw + ((st & 1) * 32 + tid) * 4) = ri;
+    }
+  };
+
   auto load_step = [&](int st) {
     const int mb = mbeg + st * 32;
 #pragma unroll
@@ -89,17 +105,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
       ar[i] = v ? *(const f4*)(a.dy + (size_t)m * a.Cout + co) : (f4){0.f, 0.f, 0.f, 0.f};
     }
     bvalid = 0;
+    const int* rw = Rw + (st & 1) * 32 * 4;
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int m = mb + rb + RB * i;
-      bool v = tv && m < mend;
-      const int mm = v ? m : 0;
-      const int n = mm / HoWo, rem = mm - n * HoWo;
-      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-      int hn = ho * a.stride + dh, wq = wo * a.stride + dw_;
-      v = v && hn >= 0 && hn < a.Hl && wq >= 0 && wq < a.Wl;
+      const int4 ri = *(const int4*)(rw + (rb + RB * i) * 4);
+      int hn = ri.y + (int)r, wq = ri.z + s;
+      bool v = tv && ri.w && hn >= 0 && hn < a.Hl && wq >= 0 && wq < a.Wl;
       hn >>= sup; wq >>= sup;
-      const float* p = sp + ((size_t)((size_t)n * sH + hn) * sW + wq) * sC + cc;
+      const float* p = sp + ((size_t)((size_t)ri.x * sH + hn) * sW + wq) * sC + cc;
       br[i] = v ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
       bvalid |= (v ? 1u : 0u) << i;
     }
@@ -107,20 +120,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   auto store_step = [&](int buf) {
     float* as = As + buf * 32 * LA;
     float* bs = Bs + buf * 32 * LB;
+    if (a_act) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *(f4*)(as + (ra + RA * i) * LA + ua * 4) = ar[i];
+      for (int i = 0; i < PA; ++i) *(f4*)(as + (ra + RA * i) * LA + ua * 4) = ar[i];
+    }
+    if (b_act) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      f4 v = br[i];
-      if (thas) {
-        v = v * tsc + tsh;
-        if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (!((bvalid >> i) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < PB; ++i) {
+        f4 v = br[i];
+        if (thas) {
+          v = v * tsc + tsh;
+          if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (!((bvalid >> i) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+        *(f4*)(bs + (rb + RB * i) * LB + ub * 4) = v;
       }
-      *(f4*)(bs + (rb + RB * i) * LB + ub * 4) = v;
     }
   };
 
+  row_info(0);
+  row_info(1);
+  __syncthreads();
   if (nsteps > 0) {
     load_step(0);
     store_step(0);
@@ -129,9 +149,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   const int li = lane & 15, lq = lane >> 4;
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) load_step(st + 1);
-    const float* as = As + cur * 32 * LA + wa * (TA / 2) + li;
-    const float* bs = Bs + cur * 32 * LB + wb * (TB / 2) + li;
+    if (st + 1 < nsteps) load_step(st + 1);          // reads row table slot (st+1)&1
+    if (st + 2 < nsteps) row_info(st + 2);           // writes slot st&1 (last read while loading step st)
+    const float* as = As + cur * 32 * LA + wa * (TA / WA) + li;
+    const float* bs = Bs + cur * 32 * LB + wb * (TB / WB) + li;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       float af[MI], bf[NI];
@@ -154,34 +175,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int kc = b0 + wb * (TB / 2) + j * 16 + li;
+      const int kc = b0 + wb * (TB / WB) + j * 16 + li;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = a0 + wa * (TA / 2) + i * 16 + lq * 4 + e;
+        const int row = a0 + wa * (TA / WA) + i * 16 + lq * 4 + e;
         if (row < a.wrows && kc < a.Kpad) atomicAdd(a.dw + (size_t)row * a.Kpad + kc, acc[i][j][e]);
       }
     }
 }
 
-template <int TA, int TB>
-static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
+template <int TA, int TB, int WA, int WB>
+static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
   const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Kpad + TB - 1) / TB;
-  const size_t lds = (size_t)2 * 32 * (TA + 16 + TB + 16) * sizeof(float);
+  const size_t lds = (size_t)2 * 32 * (TA + 16 + TB + 16) * sizeof(float) + 2 * 32 * 4 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_igemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_igemm_kernel<TA, TB, WA, WB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_igemm_kernel<TA, TB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
+  if (prof_on()) prof_begin(cls, a.flops, st);
+  hipLaunchKernelGGL((wgrad_igemm_kernel<TA, TB, WA, WB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
+  if (prof_on()) prof_end(st);
   return hipGetLastError();
 }
 
+// tile (output channels x k-columns) chosen from the layer's Cout: 16x256, 32x256, 64x128, 128x128
 hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   WgradArgs a = a0;
   if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
-  const bool bigA = a.wrows > 64;
-  const int TA = bigA ? 128 : 64, TB = 128;
+  int TA, TB;
+  if (a.wrows <= 16) { TA = 16; TB = 256; }
+  else if (a.wrows <= 32) { TA = 32; TB = 256; }
+  else if (a.wrows <= 64) { TA = 64; TB = 128; }
+  else { TA = 128; TB = 128; }
   const int tiles = ((a.wrows + TA - 1) / TA) * ((a.Kpad + TB - 1) / TB);
   // aim for ~1024 workgroups, at least 256 pixels (8 steps) per split
   int nsplit = (1024 + tiles - 1) / tiles;
@@ -192,7 +219,12 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   msplit = (msplit + 31) & ~31;
   nsplit = (a.M + msplit - 1) / msplit;
   a.nsplit = nsplit; a.msplit = msplit;
-  return bigA ? launch_w<128, 128>(a, st) : launch_w<64, 128>(a, st);
+  switch (TA) {
+    case 16: return launch_w<16, 256, 1, 4>(a, st, 8);
+    case 32: return launch_w<32, 256, 1, 4>(a, st, 9);
+    case 64: return launch_w<64, 128, 2, 2>(a, st, 6);
+    default: return launch_w<128, 128, 2, 2>(a, st, 7);
+  }
 }
 
 }  // namespace uwm

@@ -129,9 +129,12 @@ class Unet(nn.Module):
                 node.register_buffer(leaf, self._buffer_arena.as_strided(shape, stride, off))
                 self._binfo.append((node, leaf, off, shape, stride))
                 if kind == L.KIND_BN_VAR:
-                    node.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
                     self._nbt = getattr(self, "_nbt", [])
                     self._nbt.append(node)
+        # all num_batches_tracked counters alias one int64 arena: ONE increment kernel per training forward
+        self._nbt_arena = torch.zeros(len(self._nbt), dtype=torch.long)
+        for i, node in enumerate(self._nbt):
+            node.register_buffer("num_batches_tracked", self._nbt_arena[i])
         self._grad_views = []
         self._ws = None
         self._ws_key = None
@@ -161,8 +164,7 @@ class Unet(nn.Module):
                     p.zero_()
         for node, leaf, off, shape, stride in self._binfo:
             getattr(node, leaf).fill_(1.0 if leaf == "running_var" else 0.0)
-        for node in getattr(self, "_nbt", []):
-            node.num_batches_tracked.zero_()
+        self._nbt_arena.zero_()
 
     # ------------------------------------------------------------------ device movement keeps the arena aliasing
     def _apply(self, fn, recurse=True):
@@ -178,8 +180,9 @@ class Unet(nn.Module):
             p.grad = None
         for node, leaf, off, shape, stride in self._binfo:
             node._buffers[leaf] = self._buffer_arena.as_strided(shape, stride, off)
-        for node in getattr(self, "_nbt", []):
-            node._buffers["num_batches_tracked"] = fn(node._buffers["num_batches_tracked"])
+        self._nbt_arena = fn(self._nbt_arena)
+        for i, node in enumerate(self._nbt):
+            node._buffers["num_batches_tracked"] = self._nbt_arena[i]
         self._ws = None
         self._ws_key = None
         self._bound = None
@@ -255,8 +258,7 @@ class Unet(nn.Module):
                                     C.c_void_p(ws.data_ptr()), ws.numel(), n, h, w, int(training),
                                     C.c_void_p(L.stream_ptr(x.device))), SegmentationModelError)
         if training:
-            for node in getattr(self, "_nbt", []):
-                node.num_batches_tracked += 1
+            self._nbt_arena += 1
         return logits
 
     def _backward_raw(self, dlogits: torch.Tensor, stage_begin: int = 0, stage_end: Optional[int] = None):
