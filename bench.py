@@ -120,8 +120,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.lib().uwm_prof_enable(0)
-    prof = (C.c_double * (16 * 3))()
-    ncls = L.lib().uwm_prof_collect(prof, 16)
+    prof = (C.c_double * (64 * 3))()
+    ncls = L.lib().uwm_prof_collect(prof, 64)
     loss_val = float(loss[0].item())
 
     if world > 1:

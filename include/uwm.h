@@ -143,7 +143,7 @@ int  uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float*
                   int stride, int pad, int H, int W, const float* addend, const float* mask, const float* mscale,
                   const float* mshift, float* dx, uwm_stream stream);
 int  uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, int Ho, int Wo, int Cout, int wrows,
-                  int Kpad, int kh, int kw, int stride, int pad, float* dw, uwm_stream stream);
+                  int Kpad, int kh, int kw, int stride, int pad, float* dw, int force_igemm, uwm_stream stream);
 int  uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,
                        uwm_stream stream);
 int  uwm_op_maxpool(const uwm_src* in, int N, float* out, uint8_t* idx, uwm_stream stream);

@@ -65,6 +65,14 @@ def test_conv3x3_all_tile_configs(cuda, cfg):
     _conv_case(cuda, 2, 64, 64, 24, 40, 3, 1, 1, cfg=cfg)
 
 
+@pytest.mark.parametrize("bn,cout", [(16, 16), (32, 32), (64, 64), (128, 128), (64, 96), (128, 256)])
+def test_conv_patch_tile_configs(cuda, bn, cout):
+    """patch-tiled 3x3 kernel (conv_patch.hip), every channel-tile config; 24x40 pixels -> partial
+    8x16 tiles in W; Cout 96 over-hangs the 64-channel tile."""
+    _conv_case(cuda, 2, 64, cout, 24, 40, 3, 1, 1, cfg=100 + bn)
+    _conv_case(cuda, 1, 32, cout, 8, 16, 3, 1, 1, cfg=100 + bn, lazy=True, seed=2)
+
+
 @pytest.mark.parametrize("shape", [
     (2, 3, 64, 64, 64, 7, 2, 3),      # stem: Cin 3->4 pad, 7x7 s2, K=196->224
     (2, 64, 128, 32, 32, 3, 2, 1),    # layer2.0.conv1: stride 2
@@ -116,8 +124,12 @@ def test_conv_upsample_concat(cuda):
     (2, 64, 128, 32, 32, 1, 2, 0),
     (1, 16, 1, 32, 32, 3, 1, 1),      # head dgrad: dy has 1 -> 4 padded channels
     (1, 96, 32, 16, 16, 3, 1, 1),     # concat input (Ctot=96): dgrad output is the full dcat
+    (2, 32, 16, 24, 40, 3, 1, 1),     # wgrad_patch<16>, partial 8x16 tiles
+    (1, 64, 128, 16, 16, 3, 1, 1),    # wgrad_patch<64> with two output-channel tiles
+    (3, 64, 32, 8, 16, 3, 1, 1),      # wgrad_patch<32>, one tile per image
 ])
-def test_dgrad_and_wgrad(cuda, shape):
+@pytest.mark.parametrize("force_igemm", [0, 1])
+def test_dgrad_and_wgrad(cuda, shape, force_igemm):
     L = lib()
     n, cin, cout, h, w, k, s, p = shape
     g = torch.Generator().manual_seed(5)
@@ -143,7 +155,7 @@ def test_dgrad_and_wgrad(cuda, shape):
     dw = torch.zeros(cout, kpad, device=cuda)
     xd = nhwc(x.detach()).to(cuda)
     s0 = src(xd)
-    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, ho, wo, coutp, cout, kpad, k, k, s, p, P(dw), stream()))
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, ho, wo, coutp, cout, kpad, k, k, s, p, P(dw), force_igemm, stream()))
     torch.cuda.synchronize()
     ref_dx = (x.grad.permute(0, 2, 3, 1) + addend) * (maskt > 0)
     assert (dx.cpu() - ref_dx).abs().max() < 3e-5 * max(1.0, float(ref_dx.abs().max()))
@@ -153,10 +165,11 @@ def test_dgrad_and_wgrad(cuda, shape):
     assert (dw[:, k * k * rup(cin, 4):] == 0).all()
 
 
-def test_wgrad_lazy_upsample_concat(cuda):
+@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 32, 32), (32, 32, 64)])
+def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
     L = lib()
     g = torch.Generator().manual_seed(7)
-    n, c0, c1, cout, h, w = 2, 32, 16, 16, 8, 8
+    n, h, w = 2, 8, 8
     d = torch.randn(n, c0, h, w, generator=g)
     sk = torch.randn(n, c1, 2 * h, 2 * w, generator=g)
     sc0, sh0 = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
@@ -172,7 +185,7 @@ def test_wgrad_lazy_upsample_concat(cuda):
     dw = torch.zeros(cout, kpad, device=cuda)
     s0, s1 = src(dd, t[0], t[1], relu=1, up=1), src(skd)
     L.check(L.lib().uwm_op_wgrad(C.byref(s0), C.byref(s1), P(dyd), n, 2 * h, 2 * w, cout, cout, kpad, 3, 3, 1, 1, P(dw),
-                                 stream()))
+                                 0, stream()))
     torch.cuda.synchronize()
     got = unpack_w(dw.cpu(), cout, c0 + c1, 3, 3)
     assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))

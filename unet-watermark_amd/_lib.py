@@ -14,7 +14,7 @@ from pathlib import Path
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
-SOURCES = ["conv_igemm.hip", "wgrad_igemm.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
 
 
@@ -67,7 +67,7 @@ SIGNATURES = {
     "uwm_debug_lookup": (I, [P, C.c_char_p, C.POINTER(L), C.POINTER(L)]),
     "uwm_op_conv": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, P, P, P, I, P]),
     "uwm_op_dgrad": (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P]),
-    "uwm_op_wgrad": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, I, I, P, P]),
+    "uwm_op_wgrad": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, I, I, P, I, P]),
     "uwm_op_pack_dgrad": (I, [P, I, I, I, I, P, I, I, P]),
     "uwm_op_maxpool": (I, [C.POINTER(uwm_src), I, P, P, P]),
 }

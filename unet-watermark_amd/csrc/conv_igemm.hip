@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int lrow = lane & 15, lq = lane >> 4;
   for (int kc = 0; kc < nk; ++kc) {
     const int cur = kc & 1;
-    if (kc + 1 < nk) load_chunk(kc + 1);
+    load_chunk(kc + 1 < nk ? kc + 1 : kc);     // unconditional prefetch: single-basic-block loop body
     const float* xs = Xs + cur * BM * 32;
     const float* ws = Ws + cur * BN * 32;
 #pragma unroll
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[i][e], acc[i][j], 0, 0, 0);
     }
-    if (kc + 1 < nk) store_chunk(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);   // consumers of this step's global loads stay below the MFMA block
+    store_chunk(cur ^ 1);
     __syncthreads();
   }
 
@@ -254,6 +255,14 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int cfg = force_cfg;
+  if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);
+  if (cfg < 0 && conv_patch_applicable(a)) {
+    // patch-tiled 3x3: pick the channel tile so the launch has >= 512 workgroups when it can
+    const long sp = (long)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    int bn = a.Cout >= 128 ? 128 : (a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16));
+    if (bn == 128 && sp * ((a.Cout + 127) / 128) < 512) bn = 64;
+    return launch_conv_patch(a, st, bn);
+  }
   if (cfg < 0) {
     const long tiles128 = (long)((a.M + 127) / 128);
     if (a.Cout <= 16) cfg = 3;

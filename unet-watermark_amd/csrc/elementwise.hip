@@ -429,7 +429,9 @@ const char* prof_class_name(int cls) {
       "conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<128,64,2,2>", "conv_igemm_kernel<128,32,4,1>",
       "conv_igemm_kernel<128,16,4,1>",  "conv_igemm_kernel<64,64,2,2>",  "conv_igemm_kernel<64,128,1,4>",
       "wgrad_igemm_kernel<64,128,2,2>", "wgrad_igemm_kernel<128,128,2,2>", "wgrad_igemm_kernel<16,256,1,4>",
-      "wgrad_igemm_kernel<32,256,1,4>"};
+      "wgrad_igemm_kernel<32,256,1,4>", "conv_patch_kernel<128,2,2>", "conv_patch_kernel<64,2,2>",
+      "conv_patch_kernel<32,4,1>",      "conv_patch_kernel<16,4,1>",      "wgrad_patch_kernel<16>",
+      "wgrad_patch_kernel<32>",         "wgrad_patch_kernel<64>"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

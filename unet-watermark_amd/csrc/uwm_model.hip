@@ -720,7 +720,7 @@ int uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* 
   return 0;
 }
 int uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, int Ho, int Wo, int Cout, int wrows, int Kpad,
-                 int kh, int kw, int stride, int pad, float* dw, uwm_stream stream) {
+                 int kh, int kw, int stride, int pad, float* dw, int force_igemm, uwm_stream stream) {
   if (!s0 || !dy || !dw) return fail("uwm_op_wgrad: null argument");
   WgradArgs a; memset(&a, 0, sizeof(a));
   a.s0 = to_src(s0); a.C0 = a.s0.C;
@@ -729,6 +729,7 @@ int uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, i
   a.N = N; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.M = N * Ho * Wo;
   a.Hl = a.s0.H << a.s0.up; a.Wl = a.s0.W << a.s0.up; a.stride = stride; a.pad = pad;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  a.force_igemm = force_igemm;
   LCHK(launch_wgrad(a, (hipStream_t)stream));
   return 0;
 }

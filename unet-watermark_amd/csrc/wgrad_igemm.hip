@@ -149,24 +149,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   const int li = lane & 15, lq = lane >> 4;
   for (int st = 0; st < nsteps; ++st) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) load_step(st + 1);          // reads row table slot (st+1)&1
-    if (st + 2 < nsteps) row_info(st + 2);           // writes slot st&1 (last read while loading step st)
+    load_step(st + 1);                               // reads row table slot (st+1)&1 (rows past mend are masked)
+    row_info(st + 2);                                // writes slot st&1 (last read while loading step st)
     const float* as = As + cur * 32 * LA + wa * (TA / WA) + li;
     const float* bs = Bs + cur * 32 * LB + wb * (TB / WB) + li;
+    // fragments are read one k4-step ahead of the MFMAs that use them (register double buffer)
+    float af[2][MI], bf[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[0][i] = as[lq * LA + i * 16];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf[0][j] = bs[lq * LB + j * 16];
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
-      float af[MI], bf[NI];
+      const int cb = k4 & 1, nb = cb ^ 1;
+      if (k4 + 1 < 8) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = as[(k4 * 4 + lq) * LA + i * 16];
+        for (int i = 0; i < MI; ++i) af[nb][i] = as[((k4 + 1) * 4 + lq) * LA + i * 16];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = bs[(k4 * 4 + lq) * LB + j * 16];
+        for (int j = 0; j < NI; ++j) bf[nb][j] = bs[((k4 + 1) * 4 + lq) * LB + j * 16];
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb][i], bf[cb][j], acc[i][j], 0, 0, 0);
     }
-    if (st + 1 < nsteps) store_step(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);   // consumers of this step's global loads stay below the MFMA block
+    store_step(cur ^ 1);
     __syncthreads();
   }
 
@@ -202,6 +211,7 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
 
 // tile (output channels x k-columns) chosen from the layer's Cout: 16x256, 32x256, 64x128, 128x128
 hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
+  if (a0.force_igemm == 0 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);
   WgradArgs a = a0;
   if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int TA, TB;

@@ -1,0 +1,221 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution for gfx950 on v_mfma_f32_16x16x4_f32 with
+// the input PATCH and the dY tile resident in LDS.
+//
+//   dW[co][tap][c] = sum over pixels  dY[pixel][co] * X[pixel + tap][c]
+//
+// A workgroup (512 threads, 8 waves) owns TA output channels x one 32-channel input chunk x ALL nine
+// taps and walks a range of 8x16-pixel tiles.  Per tile it stages dY[128 px][TA] and the 10x18-pixel
+// input patch (lazy BatchNorm+ReLU, nearest x2 upsample, concat, zero padding applied once) in LDS,
+// double-buffered, and every wave accumulates 9 taps x (16 co x 32 c) in registers (72 VGPRs): a
+// dY fragment is read once per 4 pixels and reused by the 18 MFMAs of the nine taps, the tap shift is
+// only an LDS address offset.  Versus the flattened wgrad (wgrad_igemm.hip) the gathered-X traffic and
+// the loader's index/transform work per MFMA drop ~9x, and small Cout (16/32) wastes nothing:
+// waves split the output channels (TA/16 ways) and the tile's pixels (8/(TA/16) ways).
+// Partial sums are combined across workgroups (and pixel-split waves) with fp32 atomics.
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTH = 8, kTW = 16, kPW = kTW + 2, kPP = (kTH + 2) * kPW;   // 180 patch pixels
+constexpr int kPUnits = kPP * 8;                                         // 1440 16-byte units
+constexpr int kPRounds = (kPUnits + 511) / 512;                          // 3
+
+template <int TA>
+__global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) {
+  constexpr int WA = TA / 16;            // waves across output channels
+  constexpr int WK = 8 / WA;             // waves across the tile's pixels
+  constexpr int K4W = 32 / WK;           // 4-pixel steps per wave per tile
+  constexpr int YUNITS = 128 * TA / 4;   // 16-byte units of a dY tile
+  constexpr int YU = (YUNITS + 511) / 512;
+  constexpr int UPR = TA / 4;            // units per dY pixel row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Ys = smem;                      // [2][128][TA]
+  float* const Ps = smem + 2 * 128 * TA;       // [2][180][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave % WA, wk = wave / WA;
+  const int li = lane & 15, lq = lane >> 4;
+
+  // block -> (pixel-tile split, output-channel tile, input-channel chunk)
+  const int nchunk = a.Ctot >> 5;
+  const int tilesA = (a.wrows + TA - 1) / TA;
+  const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
+  const int ntiles = a.N * tilesH * tilesW;
+  int b = blockIdx.x;
+  const int cc = b % nchunk; b /= nchunk;
+  const int ta = b % tilesA; const int split = b / tilesA;
+  const int a0 = ta * TA;
+  const int t0 = split * a.msplit, t1 = min(ntiles, t0 + a.msplit);   // msplit = tiles per split here
+
+  // ---- per-thread loader constants
+  const int chu = tid & 7;                       // patch: channel unit is fixed per thread
+  const int c = cc * 32 + chu * 4;
+  const bool first = c < a.C0;
+  const float* sp = first ? a.s0.ptr : a.s1.ptr;
+  const float* ssc = first ? a.s0.scale : a.s1.scale;
+  const float* ssh = first ? a.s0.shift : a.s1.shift;
+  const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
+  const int sup = first ? a.s0.up : a.s1.up;
+  const int trelu = first ? a.s0.relu : a.s1.relu;
+  const int cl = first ? c : c - a.C0;
+  const bool thas = ssc != nullptr;
+  f4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
+  if (thas) { tsc = *(const f4*)(ssc + cl); tsh = *(const f4*)(ssh + cl); }
+
+  f4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc[t][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+
+  f4 yv[YU], pv[kPRounds];
+  unsigned pok = 0;
+
+  auto tile_load = [&](int t, bool enable) {
+    const int tw = t % tilesW; const int q = t / tilesW;
+    const int th = q % tilesH; const int n = q / tilesH;
+    const int h0 = th * kTH, w0 = tw * kTW;
+#pragma unroll
+    for (int i = 0; i < YU; ++i) {
+      const int uu = tid + 512 * i;
+      const int pix = uu / UPR, cu = uu - pix * UPR;
+      const int ho = h0 + (pix >> 4), wo = w0 + (pix & 15);
+      const int co = a0 + cu * 4;
+      const bool v = enable && uu < YUNITS && ho < a.Ho && wo < a.Wo && co < a.Cout;
+      yv[i] = v ? *(const f4*)(a.dy + ((size_t)((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    pok = 0;
+#pragma unroll
+    for (int rd = 0; rd < kPRounds; ++rd) {
+      const int u = rd * 512 + tid;
+      const int pp = u >> 3;
+      const int py = pp / kPW, px = pp - py * kPW;
+      const int hl = h0 - 1 + py, wl = w0 - 1 + px;
+      const bool v = enable && u < kPUnits && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const float* p = sp + ((size_t)((size_t)n * sH + (hl >> sup)) * sW + (wl >> sup)) * sC + cl;
+      pv[rd] = v ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
+      pok |= (v ? 1u : 0u) << rd;
+    }
+  };
+  auto tile_store = [&](int buf) {
+    float* ys = Ys + buf * 128 * TA;
+    float* ps = Ps + buf * kPP * 32;
+#pragma unroll
+    for (int i = 0; i < YU; ++i) {
+      const int uu = tid + 512 * i;
+      if (uu < YUNITS) {
+        const int pix = uu / UPR, cu = uu - pix * UPR;
+        const int su = (TA >= 32) ? (cu ^ ((pix & 1) << 2)) : cu;
+        *(f4*)(ys + pix * TA + su * 4) = yv[i];
+      }
+    }
+#pragma unroll
+    for (int rd = 0; rd < kPRounds; ++rd) {
+      const int u = rd * 512 + tid;
+      if (u < kPUnits) {
+        const int pp = u >> 3;
+        f4 v = pv[rd];
+        if (thas && ((pok >> rd) & 1u)) {
+          v = v * tsc + tsh;
+          if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        *(f4*)(ps + pp * 32 + ((chu ^ ((pp & 1) << 2)) << 2)) = v;
+      }
+    }
+  };
+
+  if (t0 < t1) {
+    tile_load(t0, true);
+    tile_store(0);
+  }
+  __syncthreads();
+
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    tile_load(t + 1 < t1 ? t + 1 : t, t + 1 < t1);          // unconditional, lane-masked prefetch
+    const float* ys = Ys + cur * 128 * TA;
+    const float* ps = Ps + cur * kPP * 32;
+#pragma unroll 2
+    for (int kk = 0; kk < K4W; ++kk) {
+      const int k4 = wk * K4W + kk;
+      const int ty = k4 >> 2, tx = (k4 & 3) * 4 + lq;       // this lane's pixel (k index = lq)
+      const int pix = ty * 16 + tx;
+      const int cof = wa * 16 + li;
+      const float af = ys[pix * TA + ((TA >= 32) ? (cof ^ ((pix & 1) << 4)) : cof)];
+      // patch pixel of tap (r,s) = pp0 + r*18 + s; its swizzle parity is parity(pp0 + s), so every tap
+      // is an immediate offset from one of two bases, and odd-s taps swap the two 16-channel halves
+      const int pp0 = ty * kPW + tx, sw0 = (pp0 & 1) << 4;
+      const float* P0 = ps + pp0 * 32 + li + sw0;
+      const float* P1 = ps + pp0 * 32 + li + 16 - sw0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int T = (r * kPW + s) * 32;
+          const float b0 = (s & 1) ? P1[T] : P0[T];
+          const float b1 = (s & 1) ? P0[T] : P1[T];
+          acc[r * 3 + s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b0, acc[r * 3 + s][0], 0, 0, 0);
+          acc[r * 3 + s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[r * 3 + s][1], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // consumers of the prefetch stay below the MFMA block
+    tile_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = co][j = c]: lane reg e -> co = lq*4 + e, c = li (+16 for the second tile)
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kcol = t * a.Ctot + cc * 32 + j * 16 + li;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = a0 + wa * 16 + lq * 4 + e;
+        if (row < a.wrows) atomicAdd(a.dw + (size_t)row * a.Kpad + kcol, acc[t][j][e]);
+      }
+    }
+}
+
+template <int TA>
+static hipError_t launch_wp(const WgradArgs& a, hipStream_t st, int cls, int nblocks) {
+  const size_t lds = (size_t)(2 * 128 * TA + 2 * kPP * 32) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_patch_kernel<TA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (prof_on()) prof_begin(cls, a.flops, st);
+  hipLaunchKernelGGL((wgrad_patch_kernel<TA>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
+  if (prof_on()) prof_end(st);
+  return hipGetLastError();
+}
+
+bool wgrad_patch_applicable(const WgradArgs& a) {
+  return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
+         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= kTH && a.Wo >= kTW;
+}
+
+hipError_t launch_wgrad_patch(const WgradArgs& a0, hipStream_t st) {
+  WgradArgs a = a0;
+  if (!wgrad_patch_applicable(a) || (a.Cout & 3)) return hipErrorInvalidValue;
+  const int TA = a.wrows <= 16 ? 16 : (a.wrows <= 32 ? 32 : 64);
+  const int nchunk = a.Ctot >> 5, tilesA = (a.wrows + TA - 1) / TA;
+  const int ntiles = a.N * ((a.Ho + kTH - 1) / kTH) * ((a.Wo + kTW - 1) / kTW);
+  // one 512-thread workgroup per CU: aim for ~3 waves of workgroups (768) for balance
+  int nsplit = (768 + nchunk * tilesA - 1) / (nchunk * tilesA);
+  if (nsplit > ntiles) nsplit = ntiles;
+  if (nsplit < 1) nsplit = 1;
+  int tps = (ntiles + nsplit - 1) / nsplit;
+  nsplit = (ntiles + tps - 1) / tps;
+  a.nsplit = nsplit; a.msplit = tps;
+  const int nblocks = nsplit * tilesA * nchunk;
+  switch (TA) {
+    case 16: return launch_wp<16>(a, st, 14, nblocks);
+    case 32: return launch_wp<32>(a, st, 15, nblocks);
+    default: return launch_wp<64>(a, st, 16, nblocks);
+  }
+}
+
+}  // namespace uwm
