@@ -1,0 +1,27 @@
+"""Time wgrad (auto-routed) on named layer shapes: N Cin Cout H W"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.util import src, P, stream
+from unet_watermark_amd import _lib as L
+dev = torch.device("cuda:0")
+shapes = {"layer1": (16, 64, 64, 128, 128), "layer2": (16, 128, 128, 64, 64), "layer3": (16, 256, 256, 32, 32),
+          "layer4": (16, 512, 512, 16, 16), "dec0c1": (16, 768, 256, 32, 32), "dec1c1": (16, 384, 128, 64, 64),
+          "dec2c1": (16, 192, 64, 128, 128), "dec3c1": (16, 128, 32, 256, 256), "dec4c1": (16, 32, 16, 512, 512)}
+force = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+for name, (n, cin, cout, h, w) in shapes.items():
+    x = torch.randn(n, h, w, cin, device=dev); dy = torch.randn(n, h, w, cout, device=dev)
+    kpad = 9 * cin
+    dw = torch.zeros(cout, kpad, device=dev)
+    s0 = src(x)
+    def run():
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dy), n, h, w, cout, cout, kpad, 3, 3, 1, 1, P(dw), force, stream()))
+    for _ in range(2): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    fl = 2.0 * n * h * w * cout * cin * 9
+    print(f"{name:8s} force_igemm={force} {ms*1e3:8.1f} us  {fl/ms/1e9:7.2f} TF/s")

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
           v = v * tsc + tsh;
           if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
-        *(f4*)(ps + pp * 32 + ((chu ^ ((pp & 1) << 2)) << 2)) = v;
+        *(f4*)(ps + pp * 32 + (chu << 2)) = v;      // natural layout: b64 fragment reads are conflict-free
       }
     }
   };
@@ -135,51 +135,82 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
     tile_load(t + 1 < t1 ? t + 1 : t, t + 1 < t1);          // unconditional, lane-masked prefetch
     const float* ys = Ys + cur * 128 * TA;
     const float* ps = Ps + cur * kPP * 32;
-#pragma unroll 2
-    for (int kk = 0; kk < K4W; ++kk) {
+    // Fragment reads run ONE k4-step ahead of the MFMAs (explicit register double buffer + scheduling
+    // fences): hipcc otherwise emits read -> lgkmcnt(0) -> 2 MFMAs per tap and exposes the LDS latency
+    // nine times per step.  MFMA tile 0 takes the EVEN channels (column li <-> channel 2*li), tile 1 the
+    // ODD ones, so both B fragments of a tap are one 8-byte read at an immediate offset from one base
+    // (lanes 0-15 cover a pixel's 128 B, lanes 16-31 the next pixel: conflict-free, no swizzle).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 bb[2][9]; float af[2];
+    auto frag_read = [&](int kk, int slot) {
       const int k4 = wk * K4W + kk;
       const int ty = k4 >> 2, tx = (k4 & 3) * 4 + lq;       // this lane's pixel (k index = lq)
       const int pix = ty * 16 + tx;
       const int cof = wa * 16 + li;
-      const float af = ys[pix * TA + ((TA >= 32) ? (cof ^ ((pix & 1) << 4)) : cof)];
-      // patch pixel of tap (r,s) = pp0 + r*18 + s; its swizzle parity is parity(pp0 + s), so every tap
-      // is an immediate offset from one of two bases, and odd-s taps swap the two 16-channel halves
-      const int pp0 = ty * kPW + tx, sw0 = (pp0 & 1) << 4;
-      const float* P0 = ps + pp0 * 32 + li + sw0;
-      const float* P1 = ps + pp0 * 32 + li + 16 - sw0;
+      af[slot] = ys[pix * TA + ((TA >= 32) ? (cof ^ ((pix & 1) << 4)) : cof)];
+      const float* P0 = ps + (ty * kPW + tx) * 32 + 2 * li;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const int T = (r * kPW + s) * 32;
-          const float b0 = (s & 1) ? P1[T] : P0[T];
-          const float b1 = (s & 1) ? P0[T] : P1[T];
-          acc[r * 3 + s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b0, acc[r * 3 + s][0], 0, 0, 0);
-          acc[r * 3 + s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[r * 3 + s][1], 0, 0, 0);
-        }
+        for (int s = 0; s < 3; ++s) bb[slot][r * 3 + s] = *(const f2*)(P0 + (r * kPW + s) * 32);
+    };
+    frag_read(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < K4W; ++kk) {
+      const int cb = kk & 1;
+      if (kk + 1 < K4W) frag_read(kk + 1, cb ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        acc[t9][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb], bb[cb][t9].x, acc[t9][0], 0, 0, 0);
+        acc[t9][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb], bb[cb][t9].y, acc[t9][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);   // consumers of the prefetch stay below the MFMA block
     tile_store(cur ^ 1);
     __syncthreads();
   }
 
-  // D[i = co][j = c]: lane reg e -> co = lq*4 + e, c = li (+16 for the second tile)
+  // ---- combine the 8 waves' partial tiles in LDS (ds_add_f32), then ONE coalesced pass of global atomics
+  // tile layout in LDS: [TA co][9 taps][32 c]   (the staging buffers are dead after the last barrier)
+  float* const Rt = smem;
+  constexpr int RT = TA * 288;
+  // pixel-split wave 0 stores its tile, the other WK-1 waves add theirs (no zeroing pass)
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kcol = t * a.Ctot + cc * 32 + j * 16 + li;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = a0 + wa * 16 + lq * 4 + e;
-        if (row < a.wrows) atomicAdd(a.dw + (size_t)row * a.Kpad + kcol, acc[t][j][e]);
+        const int co = wa * 16 + lq * 4 + e;                 // D row = output channel
+        if (wk == 0) Rt[co * 288 + t * 32 + 2 * li + j] = acc[t][j][e];   // D column li -> channel 2*li + j
       }
-    }
+  __syncthreads();
+  if (wk != 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = wa * 16 + lq * 4 + e;
+          atomicAdd(Rt + co * 288 + t * 32 + 2 * li + j, acc[t][j][e]);
+        }
+  }
+  __syncthreads();
+  for (int i = tid; i < RT; i += 512) {
+    const int co = i / 288, rem = i - co * 288;
+    const int t = rem >> 5, cch = rem & 31;
+    const int row = a0 + co;
+    if (row < a.wrows) atomicAdd(a.dw + (size_t)row * a.Kpad + t * a.Ctot + cc * 32 + cch, Rt[i]);
+  }
 }
 
 template <int TA>
 static hipError_t launch_wp(const WgradArgs& a, hipStream_t st, int cls, int nblocks) {
-  const size_t lds = (size_t)(2 * 128 * TA + 2 * kPP * 32) * sizeof(float);
+  size_t lds = (size_t)(2 * 128 * TA + 2 * kPP * 32) * sizeof(float);
+  if (lds < (size_t)TA * 288 * sizeof(float)) lds = (size_t)TA * 288 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)wgrad_patch_kernel<TA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -203,8 +234,23 @@ hipError_t launch_wgrad_patch(const WgradArgs& a0, hipStream_t st) {
   const int TA = a.wrows <= 16 ? 16 : (a.wrows <= 32 ? 32 : 64);
   const int nchunk = a.Ctot >> 5, tilesA = (a.wrows + TA - 1) / TA;
   const int ntiles = a.N * ((a.Ho + kTH - 1) / kTH) * ((a.Wo + kTW - 1) / kTW);
-  // one 512-thread workgroup per CU: aim for ~3 waves of workgroups (768) for balance
-  int nsplit = (768 + nchunk * tilesA - 1) / (nchunk * tilesA);
+  // Pixel-tile split: every workgroup ends with a TAx288 LDS-reduce + global-atomic epilogue worth about E
+  // tiles of work, and workgroups run in rounds of `slots` (1 resident per CU for TA=64, 2 otherwise).
+  // Pick the split that minimises rounds * (tiles_per_workgroup + E).
+  static int cus = 0;
+  if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+  const int pairs = nchunk * tilesA;
+  const int slots = cus * (TA == 64 ? 1 : 2);
+  const double E = TA == 64 ? 2.0 : (TA == 32 ? 1.0 : 0.5);
+  int nsplit = 1; double best = 1e30;
+  for (int ns = 1; ns <= ntiles && ns <= 1024; ++ns) {
+    const int tp = (ntiles + ns - 1) / ns;
+    const int nsr = (ntiles + tp - 1) / tp;
+    const long blocks = (long)pairs * nsr;
+    const long rounds = (blocks + slots - 1) / slots;
+    const double cost = (double)rounds * (tp + E);
+    if (cost < best - 1e-9) { best = cost; nsplit = nsr; }
+  }
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
   int tps = (ntiles + nsplit - 1) / nsplit;
