@@ -285,3 +285,40 @@ def test_full_size_properties_bs16_512(cuda):
     for _ in range(3):
         l1 = tr.step(x, t)[0].item()
     assert l1 < l0                               # the step optimises the Dice loss
+
+
+def test_predictor_hipgraph_matches_eager_and_bs1(cuda):
+    """BASELINE config 5 semantics: a hipGraph replay of the eval forward equals the eager call bit for bit,
+    and each image of a batch equals its own batch-1 prediction (predict.py runs batch 1)."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd.predict import WatermarkPredictor
+    from unet_watermark_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults(); cfg.MODEL.ENCODER_NAME = "resnet18"
+    torch.manual_seed(1)
+    pred = WatermarkPredictor(config=cfg, device="cuda")
+    x = torch.randn(4, 3, 128, 96, device=cuda)
+    eager = pred.logits(x, use_graph=False).clone()
+    g1 = pred.logits(x, use_graph=True).clone()
+    x2 = torch.randn(4, 3, 128, 96, device=cuda)
+    g2 = pred.logits(x2, use_graph=True).clone()            # second replay with new input
+    assert torch.equal(eager, g1)
+    assert torch.equal(g2, pred.logits(x2, use_graph=False))
+    singles = torch.cat([pred.logits(x[i:i + 1], use_graph=False) for i in range(4)], 0)
+    assert torch.equal(singles, eager)
+    m = pred.predict_mask(x)
+    assert m.dtype == torch.uint8 and m.shape == (4, 128, 96) and set(m.unique().tolist()) <= {0, 255}
+    assert torch.equal(m, ((eager[:, 0] > 0.5).to(torch.uint8) * 255))
+    u8 = torch.randint(0, 256, (2, 64, 64, 3), dtype=torch.uint8)
+    xp = pred.preprocess(u8)
+    assert xp.shape == (2, 3, 64, 64) and xp.dtype == torch.float32
+
+
+def test_cli_train_on_synthetic_learns(cuda, tmp_path):
+    from unet_watermark_amd import cli
+    hist = cli.main(["train", "--epochs", "3", "--batch-size", "4", "--lr", "0.002", "--no-early-stopping",
+                     "--synthetic", "32", "--img-size", "64", "--encoder", "resnet18", "--workers", "0",
+                     "--model-save-path", str(tmp_path / "best.pth")])
+    assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
+    from unet_watermark_amd.checkpoint import load_checkpoint
+    ck = load_checkpoint(str(tmp_path / "best.pth"))
+    assert "encoder.conv1.weight" in ck["model_state_dict"] and ck["config"]["MODEL"]["ENCODER_NAME"] == "resnet18"

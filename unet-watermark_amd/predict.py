@@ -1,0 +1,68 @@
+"""Batched mask prediction — counterpart of WatermarkPredictor._load_unet_model / predict_mask /
+step1_batch_predict_watermark_masks (/root/reference/src/predict.py:68-99,303-368,560-664) for the model
+part of that path: checkpoint -> eval() -> logits -> threshold -> uint8 mask.  The reference runs batch 1
+per image; here a whole batch goes through ONE hipGraph replay of the eval forward (BASELINE config 5).
+OpenCV post-processing / IOPaint / OCR stay out of scope."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .checkpoint import load_checkpoint
+from .config import get_cfg_defaults, update_config
+from .metrics import threshold_mask
+from .model import create_model_from_config
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class WatermarkPredictor:
+    def __init__(self, model_path: Optional[str] = None, config_path: Optional[str] = None, config=None,
+                 device: str = "cuda", model=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("WatermarkPredictor runs only on a HIP device (no CPU fallback)")
+        self.cfg = config if config is not None else get_cfg_defaults()
+        if config_path:
+            update_config(self.cfg, config_path)
+        self.model = model if model is not None else create_model_from_config(self.cfg)
+        if model_path:
+            load_checkpoint(model_path, self.model)
+        self.model.to(self.device).eval()
+        self.threshold = float(self.cfg.PREDICT.THRESHOLD)
+        self._graph = None
+        self._gkey = None
+        self._gin = self._gout = None
+
+    # --- input contract of dataset.get_val_transform: Resize -> Normalize(ImageNet) -> NCHW fp32
+    def preprocess(self, images_u8_nhwc: torch.Tensor) -> torch.Tensor:
+        x = images_u8_nhwc.to(self.device).permute(0, 3, 1, 2).float().div_(255.0)
+        mean = torch.tensor(IMAGENET_MEAN, device=self.device).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_STD, device=self.device).view(1, 3, 1, 1)
+        return ((x - mean) / std).contiguous()
+
+    @torch.no_grad()
+    def logits(self, x: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
+        """x (N,3,H,W) fp32 on the device -> logits (N,1,H,W).  With use_graph the eval forward of this
+        batch shape is captured once into a hipGraph and replayed (static input/output buffers)."""
+        if not use_graph:
+            return self.model(x)
+        key = tuple(x.shape)
+        if self._gkey != key:
+            self._gin = x.clone()
+            self.model(self._gin)                     # eager warm-up: plans the workspace, sets kernel attributes
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._gout = self.model(self._gin)
+            self._graph, self._gkey = g, key
+        self._gin.copy_(x)
+        self._graph.replay()
+        return self._gout
+
+    @torch.no_grad()
+    def predict_mask(self, x: torch.Tensor, apply_sigmoid: bool = False, use_graph: bool = True) -> torch.Tensor:
+        """-> uint8 {0,255} (N,H,W); default reproduces predict.py:624 (raw logits > THRESHOLD)."""
+        return threshold_mask(self.logits(x, use_graph), self.threshold, apply_sigmoid)
