@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +68,11 @@ struct uwm_model {
   size_t fixed_floats = 0;           // fixed workspace region (BN scratch + dgrad packs), in floats
   Plan plan;
   bool have_fwd = false;
+  // weight-gradient kernels run on an internal side stream, forked from / joined to the caller's stream
+  // with events (capturable fork-join; no host synchronisation)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int use_side = 1;
 };
 
 static int add_bn(uwm_model* m, const std::string& name, int C, int stage) {
@@ -259,6 +265,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
 // ------------------------------------------------------------------------------ launch helpers
 struct Ctx {
   uwm_model* m; float* ws; hipStream_t st; int N;
+  hipStream_t wst = nullptr;          // stream for wgrad launches (== st when the side stream is off)
   float* F(size_t off) const { return ws + off; }
   double* D(size_t doff) const { return (double*)ws + doff; }
 };
@@ -314,6 +321,14 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.Hl = s0.H << s0.up; a.Wl = s0.W << s0.up; a.stride = cv.stride; a.pad = cv.pad;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
+  if (c.wst && c.wst != c.st) {
+    // fork: the side stream must see everything enqueued so far on the main stream (dy, activations)
+    hipError_t e = hipEventRecord(c.m->ev_fork, c.st);
+    if (e != hipSuccess) return e;
+    e = hipStreamWaitEvent(c.wst, c.m->ev_fork, 0);
+    if (e != hipSuccess) return e;
+    return launch_wgrad(a, c.wst);
+  }
   return launch_wgrad(a, c.st);
 }
 
@@ -413,6 +428,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
   const Plan& p = m->plan;
   const int N = p.N, H = p.H, W = p.W;
   Ctx c{m, ws, st, N};
+  c.wst = (m->use_side && m->side) ? m->side : st;
   // geometry
   const int h1 = H / 2, w1 = W / 2;          // f1
   int sh[4], sw[4];
@@ -506,6 +522,10 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       LCHK(run_wgrad(c, m->stem, x4, nullptr, c.F(p.g[m->stem]), h1, w1));
     }
   }
+  if (c.wst != st) {                    // join: the caller's stream waits for every wgrad of these stages
+    HIPCHK(hipEventRecord(m->ev_join, c.wst));
+    HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+  }
   return 0;
 }
 
@@ -522,9 +542,17 @@ int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
   if (m->desc.bn_eps <= 0.f) m->desc.bn_eps = 1e-5f;
   if (m->desc.bn_momentum <= 0.f) m->desc.bn_momentum = 0.1f;
   if (build_model(m)) { delete m; return 1; }
+  const char* e = getenv("UWM_SIDE_STREAM");
+  m->use_side = e ? atoi(e) : 1;
   *out = m; return 0;
 }
-void uwm_destroy(uwm_handle h) { delete h; }
+void uwm_destroy(uwm_handle h) {
+  if (!h) return;
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  delete h;
+}
 
 long long uwm_param_arena_floats(uwm_handle h) { return h ? h->param_floats : 0; }
 long long uwm_buffer_arena_floats(uwm_handle h) { return h ? h->buffer_floats : 0; }
@@ -543,7 +571,15 @@ int uwm_stage_range(uwm_handle h, int stage, long long* b, long long* e) {
 int uwm_bind(uwm_handle h, float* params, float* grads, float* buffers) {
   if (!h || !params || !buffers) return fail("uwm_bind: params and buffers must be non-null");
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)buffers) & 15) return fail("uwm_bind: arenas must be 16-byte aligned");
-  h->params = params; h->grads = grads; h->buffers = buffers; return 0;
+  h->params = params; h->grads = grads; h->buffers = buffers;
+  if (h->use_side && !h->side) {        // created lazily on the device the arenas live on (current device)
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; (void)hipGetLastError(); }
+    else if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(h->side); h->side = nullptr; (void)hipGetLastError();
+    }
+  }
+  return 0;
 }
 
 static int check_shape(int N, int H, int W) {
