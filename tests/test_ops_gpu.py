@@ -73,6 +73,14 @@ def test_conv_patch_tile_configs(cuda, bn, cout):
     _conv_case(cuda, 1, 32, cout, 8, 16, 3, 1, 1, cfg=100 + bn, lazy=True, seed=2)
 
 
+@pytest.mark.parametrize("cout", [16, 1, 32])
+def test_conv_patch16(cuda, cout):
+    """16-channel-input kernel (whole K=144 in LDS): decoder block 4 conv2 / head / dcat-dgrad shapes;
+    40x24 pixels -> partial 16x16 tiles; lazy BatchNorm+ReLU input."""
+    _conv_case(cuda, 2, 16, cout, 40, 24, 3, 1, 1, cfg=200)
+    _conv_case(cuda, 1, 16, cout, 16, 16, 3, 1, 1, cfg=200, lazy=True, seed=4)
+
+
 @pytest.mark.parametrize("shape", [
     (2, 3, 64, 64, 64, 7, 2, 3),      # stem: Cin 3->4 pad, 7x7 s2, K=196->224
     (2, 64, 128, 32, 32, 3, 2, 1),    # layer2.0.conv1: stride 2
@@ -127,6 +135,8 @@ def test_conv_upsample_concat(cuda):
     (2, 32, 16, 24, 40, 3, 1, 1),     # wgrad_patch<16>, partial 8x16 tiles
     (1, 64, 128, 16, 16, 3, 1, 1),    # wgrad_patch<64> with two output-channel tiles
     (3, 64, 32, 8, 16, 3, 1, 1),      # wgrad_patch<32>, one tile per image
+    (1, 32, 16, 32, 48, 3, 1, 1),     # dgrad runs conv_patch16<32> (dy has 16 channels)
+    (2, 16, 16, 16, 32, 3, 1, 1),     # dgrad runs conv_patch16<16>
 ])
 @pytest.mark.parametrize("force_igemm", [0, 1])
 def test_dgrad_and_wgrad(cuda, shape, force_igemm):

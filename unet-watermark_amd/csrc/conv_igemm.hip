@@ -255,7 +255,9 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int cfg = force_cfg;
+  if (cfg == 200) return launch_conv_patch16(a, st);
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);
+  if (cfg < 0 && conv_patch16_applicable(a)) return launch_conv_patch16(a, st);
   if (cfg < 0 && conv_patch_applicable(a)) {
     // patch-tiled 3x3: pick the channel tile so the launch has >= 512 workgroups when it can
     const long sp = (long)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);

@@ -1,0 +1,184 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and dgrad) for inputs with exactly 16 channels on gfx950
+// (v_mfma_f32_16x16x4_f32): the full-resolution tail of the decoder (decoder block 4 conv2, the
+// segmentation head, and every dgrad whose incoming gradient has 16 channels).
+//
+// K = 9 taps x 16 channels = 144 is so small that nothing needs a K loop: a workgroup stages the WHOLE
+// weight panel [BN][144] (9 KB for BN=16) and one 16-channel 18x18-pixel halo patch (20 KB) in LDS once,
+// passes ONE barrier, and runs 9 taps x (4 pixel rows x NI channel tiles) x 4 MFMAs per wave straight out
+// of LDS; tap (r,s) is an LDS address offset.  ~30 KB of LDS and < 100 VGPRs per workgroup put 5 workgroups
+// on a CU, so the loads of one overlap the MFMAs of the others.  The flattened implicit GEMM needed a
+// barrier every 8-16 MFMAs on these layers (20 TFLOP/s, profiles/r01_d).
+// Loader / epilogue contracts are those of conv_igemm.hip (lazy BatchNorm+ReLU input, bias, residual
+// addend, ReLU mask, BatchNorm statistics).
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kT = 16, kP = kT + 2, kPPix = kP * kP;      // 16x16 output pixels, 18x18 = 324 patch pixels
+constexpr int kWLd = 148;                                  // weight row stride in floats (37 16-B units: odd)
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
+  constexpr int NI = BN / 16;
+  constexpr int MI = 4;                          // 4 waves x 4 pixel rows
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Ps = smem;                        // [324][16]
+  float* const Ws = smem + kPPix * 16;           // [BN][148]
+
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesN = (a.Cout + BN - 1) / BN;
+  const int tilesW = (a.Wo + kT - 1) / kT, tilesH = (a.Ho + kT - 1) / kT;
+  const int tn = tile % tilesN; tile /= tilesN;
+  const int tw = tile % tilesW; tile /= tilesW;
+  const int th = tile % tilesH; const int n = tile / tilesH;
+  const int n0 = tn * BN, h0 = th * kT, w0 = tw * kT;
+  const bool mirror = a.rmul < 0;                // dgrad: tap (r,s) reads patch (ty+2-r, tx+2-s)
+
+  // ---- stage the patch: 324 pixels x 4 units
+  const bool has = a.s0.scale != nullptr;
+  for (int u = tid; u < kPPix * 4; u += 256) {
+    const int pp = u >> 2, chu = u & 3;
+    const int py = pp / kP, px = pp - py * kP;
+    const int hl = h0 - 1 + py, wl = w0 - 1 + px;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl) {
+      v = *(const f4*)(a.s0.ptr + ((size_t)((size_t)n * a.s0.H + hl) * a.s0.W + wl) * a.s0.C + chu * 4);
+      if (has) {
+        v = v * *(const f4*)(a.s0.scale + chu * 4) + *(const f4*)(a.s0.shift + chu * 4);
+        if (a.s0.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+    }
+    *(f4*)(Ps + pp * 16 + ((chu ^ ((pp >> 2) & 3)) << 2)) = v;
+  }
+  // ---- stage the weight panel: BN rows x 36 units (k = tap*16 + c)
+  for (int u = tid; u < BN * 36; u += 256) {
+    const int row = u / 36, ku = u - row * 36;
+    const int co = n0 + row;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (co < a.wrows) v = *(const f4*)(a.w + (size_t)co * a.Kpad + ku * 4);
+    *(f4*)(Ws + row * kWLd + ku * 4) = v;
+  }
+  __syncthreads();
+
+  f4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int r = tap / 3, s = tap - r * 3;
+    const int rr = mirror ? 2 - r : r, ss = mirror ? 2 - s : s;
+    f4 xf[MI], wf[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int pp = (wm * MI + i + rr) * kP + lrow + ss;
+      xf[i] = *(const f4*)(Ps + pp * 16 + ((lq ^ ((pp >> 2) & 3)) << 2));
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wf[j] = *(const f4*)(Ws + (j * 16 + lrow) * kWLd + tap * 16 + lq * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[i][e], acc[i][j], 0, 0, 0);
+  }
+
+  // ---------------- epilogue (same contract as conv_igemm_kernel) ----------------
+  const bool do_stats = a.ssum != nullptr;
+  f4 ps_[NI], pq_[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { ps_[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq_[j] = ps_[j]; }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int ho = h0 + wm * MI + i, wo = w0 + lrow;
+    const bool pin = ho < a.Ho && wo < a.Wo;
+    const size_t m = ((size_t)n * a.Ho + ho) * a.Wo + wo;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int co = n0 + j * 16 + lq * 4;
+      if (pin && co < a.Cout) {
+        f4 v = acc[i][j];
+        const size_t o = m * a.Cout + co;
+        if (a.bias) v += *(const f4*)(a.bias + co);
+        if (a.addend) v += *(const f4*)(a.addend + o);
+        if (a.mask) {
+          f4 mk = *(const f4*)(a.mask + o);
+          if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        *(f4*)(a.out + o) = v;
+        ps_[j] += v; pq_[j] += v * v;
+      }
+    }
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sv = ps_[j][e], qv = pq_[j][e];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { sv += __shfl_xor(sv, d); qv += __shfl_xor(qv, d); }
+        ps_[j][e] = sv; pq_[j][e] = qv;
+      }
+    __syncthreads();                         // everyone is done reading the patch / weights
+    float* red = smem;                       // [4 waves][BN][2]
+    if (lrow == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cl = j * 16 + lq * 4 + e;
+          red[(wm * BN + cl) * 2 + 0] = ps_[j][e];
+          red[(wm * BN + cl) * 2 + 1] = pq_[j][e];
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = n0 + tid;
+      if (co < a.Cout) {
+        double sv = 0.0, qv = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sv += (double)red[(w * BN + tid) * 2]; qv += (double)red[(w * BN + tid) * 2 + 1]; }
+        atomicAdd(a.ssum + co, sv);
+        atomicAdd(a.ssq + co, qv);
+      }
+    }
+  }
+}
+
+template <int BN>
+static hipError_t launch_p16(const ConvArgs& a, hipStream_t st, int cls) {
+  const int tilesN = (a.Cout + BN - 1) / BN;
+  const int tilesW = (a.Wo + kT - 1) / kT, tilesH = (a.Ho + kT - 1) / kT;
+  const size_t lds = (size_t)(kPPix * 16 + BN * kWLd) * sizeof(float);
+  if (prof_on()) prof_begin(cls, a.flops, st);
+  hipLaunchKernelGGL((conv_patch16_kernel<BN>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+  if (prof_on()) prof_end(st);
+  return hipGetLastError();
+}
+
+bool conv_patch16_applicable(const ConvArgs& a) {
+  return a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && (a.rmul == 1 ? a.off == -1 : a.off == 1) &&
+         a.Ctot == 16 && a.C0 == 16 && a.s0.C == 16 && a.s0.up == 0 && a.Kpad >= 144 &&
+         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= kT && a.Wo >= kT;
+}
+
+hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st) {
+  if (!conv_patch16_applicable(a) || (a.Cout & 3)) return hipErrorInvalidValue;
+  return a.Cout > 16 ? launch_p16<32>(a, st, 18) : launch_p16<16>(a, st, 17);
+}
+
+}  // namespace uwm

@@ -60,8 +60,8 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
-// 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64
-enum { kProfClasses = 17 };
+// 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
+enum { kProfClasses = 19 };
 void prof_enable(bool on);
 bool prof_on();
 void prof_begin(int cls, double flops, hipStream_t st);
@@ -73,10 +73,12 @@ const char* prof_class_name(int cls);
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg = -1);
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st);
 // 3x3 s1 p1 patch-tiled conv (conv_patch.hip); launch_conv routes to it when applicable.
-// force_cfg for launch_conv: -1 auto, 0..5 conv_igemm tile config, 100+BN (116,132,164,228) conv_patch
+// force_cfg for launch_conv: -1 auto, 0..5 conv_igemm tile config, 100+BN (116,132,164,228) conv_patch, 200 conv_patch16
 bool wgrad_patch_applicable(const WgradArgs& a);
 hipError_t launch_wgrad_patch(const WgradArgs& a, hipStream_t st);
 bool conv_patch_applicable(const ConvArgs& a);
+bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
+hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);
 hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn);
 
 hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st);
