@@ -22,7 +22,9 @@ constexpr int kTH = 8, kTW = 16, kPW = kTW + 2, kPP = (kTH + 2) * kPW;   // 180 
 constexpr int kPUnits = kPP * 8;                                         // 1440 16-byte units
 constexpr int kPRounds = (kPUnits + 511) / 512;                          // 3
 
-template <int TA>
+// CW = input channels per workgroup chunk: 32 (two MFMA column tiles: even / odd channels) or 16 (one tile,
+// the 16-channel layers at full resolution)
+template <int TA, int CW>
 __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) {
   constexpr int WA = TA / 16;            // waves across output channels
   constexpr int WK = 8 / WA;             // waves across the tile's pixels
@@ -30,16 +32,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
   constexpr int YUNITS = 128 * TA / 4;   // 16-byte units of a dY tile
   constexpr int YU = (YUNITS + 511) / 512;
   constexpr int UPR = TA / 4;            // units per dY pixel row
+  constexpr int NJ = CW / 16;            // MFMA column tiles (input-channel tiles)
+  constexpr int PU = CW / 4;             // 16-byte units per patch pixel
+  constexpr int PUNITS = kPP * PU, PROUNDS = (PUNITS + 511) / 512;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ys = smem;                      // [2][128][TA]
-  float* const Ps = smem + 2 * 128 * TA;       // [2][180][32]
+  float* const Ps = smem + 2 * 128 * TA;       // [2][180][CW]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave % WA, wk = wave / WA;
   const int li = lane & 15, lq = lane >> 4;
 
   // block -> (pixel-tile split, output-channel tile, input-channel chunk)
-  const int nchunk = a.Ctot >> 5;
+  const int nchunk = a.Ctot / CW;
   const int tilesA = (a.wrows + TA - 1) / TA;
   const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
   const int ntiles = a.N * tilesH * tilesW;
@@ -50,8 +55,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
   const int t0 = split * a.msplit, t1 = min(ntiles, t0 + a.msplit);   // msplit = tiles per split here
 
   // ---- per-thread loader constants
-  const int chu = tid & 7;                       // patch: channel unit is fixed per thread
-  const int c = cc * 32 + chu * 4;
+  const int chu = tid % PU;                      // patch: channel unit is fixed per thread (512 % PU == 0)
+  const int c = cc * CW + chu * 4;
   const bool first = c < a.C0;
   const float* sp = first ? a.s0.ptr : a.s1.ptr;
   const float* ssc = first ? a.s0.scale : a.s1.scale;
@@ -64,11 +69,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
   f4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
   if (thas) { tsc = *(const f4*)(ssc + cl); tsh = *(const f4*)(ssh + cl); }
 
-  f4 acc[9][2];
+  f4 acc[9][NJ];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) { acc[t][0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[t][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  f4 yv[YU], pv[kPRounds];
+  f4 yv[YU], pv[PROUNDS];
   unsigned pok = 0;
 
   auto tile_load = [&](int t, bool enable) {
@@ -86,12 +93,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
     }
     pok = 0;
 #pragma unroll
-    for (int rd = 0; rd < kPRounds; ++rd) {
+    for (int rd = 0; rd < PROUNDS; ++rd) {
       const int u = rd * 512 + tid;
-      const int pp = u >> 3;
+      const int pp = u / PU;
       const int py = pp / kPW, px = pp - py * kPW;
       const int hl = h0 - 1 + py, wl = w0 - 1 + px;
-      const bool v = enable && u < kPUnits && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const bool v = enable && u < PUNITS && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
       const float* p = sp + ((size_t)((size_t)n * sH + (hl >> sup)) * sW + (wl >> sup)) * sC + cl;
       pv[rd] = v ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
       pok |= (v ? 1u : 0u) << rd;
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
   };
   auto tile_store = [&](int buf) {
     float* ys = Ys + buf * 128 * TA;
-    float* ps = Ps + buf * kPP * 32;
+    float* ps = Ps + buf * kPP * CW;
 #pragma unroll
     for (int i = 0; i < YU; ++i) {
       const int uu = tid + 512 * i;
@@ -110,16 +117,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
       }
     }
 #pragma unroll
-    for (int rd = 0; rd < kPRounds; ++rd) {
+    for (int rd = 0; rd < PROUNDS; ++rd) {
       const int u = rd * 512 + tid;
-      if (u < kPUnits) {
-        const int pp = u >> 3;
+      if (u < PUNITS) {
+        const int pp = u / PU;
         f4 v = pv[rd];
         if (thas && ((pok >> rd) & 1u)) {
           v = v * tsc + tsh;
           if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
-        *(f4*)(ps + pp * 32 + (chu << 2)) = v;      // natural layout: b64 fragment reads are conflict-free
+        *(f4*)(ps + pp * CW + (chu << 2)) = v;      // natural layout: b64 (CW=32) / b32 (CW=16) fragment reads are conflict-free
       }
     }
   };
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
     const int cur = (t - t0) & 1;
     tile_load(t + 1 < t1 ? t + 1 : t, t + 1 < t1);          // unconditional, lane-masked prefetch
     const float* ys = Ys + cur * 128 * TA;
-    const float* ps = Ps + cur * kPP * 32;
+    const float* ps = Ps + cur * kPP * CW;
     // Fragment reads run ONE k4-step ahead of the MFMAs (explicit register double buffer + scheduling
     // fences): hipcc otherwise emits read -> lgkmcnt(0) -> 2 MFMAs per tap and exposes the LDS latency
     // nine times per step.  MFMA tile 0 takes the EVEN channels (column li <-> channel 2*li), tile 1 the
@@ -148,11 +155,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
       const int pix = ty * 16 + tx;
       const int cof = wa * 16 + li;
       af[slot] = ys[pix * TA + ((TA >= 32) ? (cof ^ ((pix & 1) << 4)) : cof)];
-      const float* P0 = ps + (ty * kPW + tx) * 32 + 2 * li;
+      if (NJ == 2) {
+        const float* P0 = ps + (ty * kPW + tx) * CW + 2 * li;
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) bb[slot][r * 3 + s] = *(const f2*)(P0 + (r * kPW + s) * 32);
+          for (int s = 0; s < 3; ++s) bb[slot][r * 3 + s] = *(const f2*)(P0 + (r * kPW + s) * CW);
+      } else {                                   // CW = 16: column li <-> channel li, one 4-byte read per tap
+        const float* P0 = ps + (ty * kPW + tx) * CW + li;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bb[slot][r * 3 + s].x = P0[(r * kPW + s) * CW];
+      }
     };
     frag_read(0, 0);
 #pragma unroll
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
         acc[t9][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb], bb[cb][t9].x, acc[t9][0], 0, 0, 0);
-        acc[t9][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb], bb[cb][t9].y, acc[t9][1], 0, 0, 0);
+        if (NJ == 2) acc[t9][NJ - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb], bb[cb][t9].y, acc[t9][NJ - 1], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -175,56 +190,58 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
   // ---- combine the 8 waves' partial tiles in LDS (ds_add_f32), then ONE coalesced pass of global atomics
   // tile layout in LDS: [TA co][9 taps][32 c]   (the staging buffers are dead after the last barrier)
   float* const Rt = smem;
-  constexpr int RT = TA * 288;
+  constexpr int RT = TA * 9 * CW;
   // pixel-split wave 0 stores its tile, the other WK-1 waves add theirs (no zeroing pass)
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int co = wa * 16 + lq * 4 + e;                 // D row = output channel
-        if (wk == 0) Rt[co * 288 + t * 32 + 2 * li + j] = acc[t][j][e];   // D column li -> channel 2*li + j
+        if (wk == 0) Rt[co * 9 * CW + t * CW + NJ * li + j] = acc[t][j][e];   // D column li -> channel NJ*li + j
       }
   __syncthreads();
   if (wk != 0) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = wa * 16 + lq * 4 + e;
-          atomicAdd(Rt + co * 288 + t * 32 + 2 * li + j, acc[t][j][e]);
+          atomicAdd(Rt + co * 9 * CW + t * CW + NJ * li + j, acc[t][j][e]);
         }
   }
   __syncthreads();
   for (int i = tid; i < RT; i += 512) {
-    const int co = i / 288, rem = i - co * 288;
-    const int t = rem >> 5, cch = rem & 31;
+    const int co = i / (9 * CW), rem = i - co * (9 * CW);
+    const int t = rem / CW, cch = rem - t * CW;
     const int row = a0 + co;
-    if (row < a.wrows) atomicAdd(a.dw + (size_t)row * a.Kpad + t * a.Ctot + cc * 32 + cch, Rt[i]);
+    if (row < a.wrows) atomicAdd(a.dw + (size_t)row * a.Kpad + t * a.Ctot + cc * CW + cch, Rt[i]);
   }
 }
 
-template <int TA>
+template <int TA, int CW>
 static hipError_t launch_wp(const WgradArgs& a, hipStream_t st, int cls, int nblocks) {
-  size_t lds = (size_t)(2 * 128 * TA + 2 * kPP * 32) * sizeof(float);
-  if (lds < (size_t)TA * 288 * sizeof(float)) lds = (size_t)TA * 288 * sizeof(float);
+  size_t lds = (size_t)(2 * 128 * TA + 2 * kPP * CW) * sizeof(float);
+  if (lds < (size_t)TA * 9 * CW * sizeof(float)) lds = (size_t)TA * 9 * CW * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_patch_kernel<TA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_patch_kernel<TA, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((wgrad_patch_kernel<TA>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_patch_kernel<TA, CW>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
   if (prof_on()) prof_end(st);
   return hipGetLastError();
 }
 
 bool wgrad_patch_applicable(const WgradArgs& a) {
-  return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
+  const bool c32 = (a.Ctot & 31) == 0 && (a.C0 & 31) == 0;
+  const bool c16 = a.Ctot == 16 && a.C0 == 16;                  // single 16-channel source
+  return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (c32 || c16) &&
          a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= kTH && a.Wo >= kTW;
 }
 
@@ -232,7 +249,8 @@ hipError_t launch_wgrad_patch(const WgradArgs& a0, hipStream_t st) {
   WgradArgs a = a0;
   if (!wgrad_patch_applicable(a) || (a.Cout & 3)) return hipErrorInvalidValue;
   const int TA = a.wrows <= 16 ? 16 : (a.wrows <= 32 ? 32 : 64);
-  const int nchunk = a.Ctot >> 5, tilesA = (a.wrows + TA - 1) / TA;
+  const bool c16 = a.Ctot == 16;
+  const int nchunk = c16 ? 1 : a.Ctot >> 5, tilesA = (a.wrows + TA - 1) / TA;
   const int ntiles = a.N * ((a.Ho + kTH - 1) / kTH) * ((a.Wo + kTW - 1) / kTW);
   // Pixel-tile split: every workgroup ends with a TAx288 LDS-reduce + global-atomic epilogue worth about E
   // tiles of work, and workgroups run in rounds of `slots` (1 resident per CU for TA=64, 2 otherwise).
@@ -257,10 +275,11 @@ hipError_t launch_wgrad_patch(const WgradArgs& a0, hipStream_t st) {
   nsplit = (ntiles + tps - 1) / tps;
   a.nsplit = nsplit; a.msplit = tps;
   const int nblocks = nsplit * tilesA * nchunk;
+  if (c16) return TA == 16 ? launch_wp<16, 16>(a, st, 14, nblocks) : (TA == 32 ? launch_wp<32, 16>(a, st, 15, nblocks) : launch_wp<64, 16>(a, st, 16, nblocks));
   switch (TA) {
-    case 16: return launch_wp<16>(a, st, 14, nblocks);
-    case 32: return launch_wp<32>(a, st, 15, nblocks);
-    default: return launch_wp<64>(a, st, 16, nblocks);
+    case 16: return launch_wp<16, 32>(a, st, 14, nblocks);
+    case 32: return launch_wp<32, 32>(a, st, 15, nblocks);
+    default: return launch_wp<64, 32>(a, st, 16, nblocks);
   }
 }
 
