@@ -147,6 +147,19 @@ int  uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, 
 int  uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,
                        uwm_stream stream);
 int  uwm_op_maxpool(const uwm_src* in, int N, float* out, uint8_t* idx, uwm_stream stream);
+/* gin[N][H][W][C] = (maxpool3x3s2_backward(gout, idx) + addend) * [relu(in) > 0] */
+int  uwm_op_maxpool_backward(const float* gout, const uint8_t* idx, const float* addend, const uwm_src* in, int N,
+                             float* gin, uwm_stream stream);
+/* BatchNorm backward (batch statistics): g = grad wrt the BN output, y = BN input; scratch2c: 2*C doubles.
+ * dy = gamma*rstd*(g - mean(g) - yhat*mean(g*yhat)), dgamma = sum g*yhat, dbeta = sum g */
+int  uwm_op_bn_backward(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
+                        double* scratch2c, float* dy, float* dgamma, float* dbeta, long long npix, int C, uwm_stream stream);
+/* gradient of cat(nearest_x2(prev), skip): gprev[N][H/2][W/2][C0] = mask(sum 2x2 dcat[..., :C0]), gskip = dcat[..., C0:] */
+int  uwm_op_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev, const float* pmask,
+                    const float* pscale, const float* pshift, float* gskip, uwm_stream stream);
+/* out = relu(y*s2+b2 + (sd ? id*sd+bd : id)) */
+int  uwm_op_residual(const float* y, const float* s2, const float* b2, const float* id, const float* sd, const float* bd,
+                     float* out, long long npix, int C, uwm_stream stream);
 
 #ifdef __cplusplus
 }

@@ -235,3 +235,89 @@ def test_maxpool_ties_and_lazy_input(cuda):
         v1 = af.gather(2, ridx.flatten(2))[diff.flatten(2)]
         assert (v0 - v1).abs().max() <= 4e-7 * max(1.0, float(ref.abs().max()))
     assert torch.equal(flat[ref == 0], ridx[ref == 0])
+
+
+@pytest.mark.parametrize("c,n,h,w", [(16, 2, 24, 40), (64, 3, 16, 16), (512, 4, 4, 5)])
+def test_bn_backward_matches_autograd(cuda, c, n, h, w):
+    """bn_bwd_reduce + bn_bwd_apply == autograd of F.batch_norm(training=True) in fp64."""
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    y = (torch.randn(n, c, h, w, generator=g) * 2 + 0.7).double().requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).double().requires_grad_()
+    beta = torch.randn(c, generator=g).double().requires_grad_()
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    go = torch.randn(n, c, h, w, generator=g).double() + 0.5          # non-zero mean: exercises the cancellation
+    z.backward(go)
+    mean = y.detach().mean((0, 2, 3)); var = y.detach().var((0, 2, 3), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    dev = lambda t: t.float().to(cuda)
+    gd, yd = nhwc(go.float()).to(cuda), nhwc(y.detach().float()).to(cuda)
+    dy = torch.empty_like(gd); dgam = torch.empty(c, device=cuda); dbet = torch.empty(c, device=cuda)
+    scr = torch.empty(2 * c, dtype=torch.float64, device=cuda)
+    t = [dev(mean), dev(rstd), dev(gamma.detach())]
+    L.check(L.lib().uwm_op_bn_backward(P(gd), P(yd), P(t[0]), P(t[1]), P(t[2]), P(scr), P(dy), P(dgam), P(dbet), n * h * w, c,
+                                       stream()))
+    torch.cuda.synchronize()
+    ref = y.grad.float()
+    assert (nchw(dy.cpu()) - ref).abs().max() < 2e-5 * float(ref.abs().max()) + 1e-6
+    assert torch.allclose(dgam.cpu(), gamma.grad.float(), rtol=1e-4, atol=1e-4 * float(gamma.grad.abs().max()))
+    assert torch.allclose(dbet.cpu(), beta.grad.float(), rtol=1e-5, atol=1e-5 * float(beta.grad.abs().max()))
+
+
+def test_upsplit_matches_autograd(cuda):
+    L = lib()
+    g = torch.Generator().manual_seed(12)
+    n, c0, c1, h, w = 2, 32, 16, 8, 12
+    prev = torch.randn(n, c0, h, w, generator=g, requires_grad=True)
+    skip = torch.randn(n, c1, 2 * h, 2 * w, generator=g, requires_grad=True)
+    sc, sh = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.3
+    a = torch.relu(prev * sc[:, None, None] + sh[:, None, None])
+    a.retain_grad()
+    cat = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), skip], 1)
+    dcat = torch.randn(cat.shape, generator=g)
+    cat.backward(dcat)
+    # the kernel returns the gradient wrt the post-ReLU activation, masked by the ReLU: a.grad * (a > 0)
+    ref_prev = (a.grad * (a.detach() > 0)).permute(0, 2, 3, 1)
+    dd = nhwc(dcat).to(cuda); pm = nhwc(prev.detach()).to(cuda)
+    t = [sc.to(cuda), sh.to(cuda)]
+    gp = torch.empty(n, h, w, c0, device=cuda); gs = torch.empty(n, 2 * h, 2 * w, c1, device=cuda)
+    L.check(L.lib().uwm_op_upsplit(P(dd), n, 2 * h, 2 * w, c0, c1, P(gp), P(pm), P(t[0]), P(t[1]), P(gs), stream()))
+    torch.cuda.synchronize()
+    assert (gp.cpu() - ref_prev).abs().max() < 1e-5
+    assert torch.equal(gs.cpu(), skip.grad.permute(0, 2, 3, 1).contiguous())
+
+
+def test_residual_and_maxpool_backward(cuda):
+    L = lib()
+    g = torch.Generator().manual_seed(13)
+    n, c, h, w = 2, 64, 16, 24
+    # residual: relu(bn2(y2) + bn_d(yd))
+    y2, yd = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    s2, b2, sd, bd = (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2,
+                      torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2)
+    bc = lambda v: v[None, :, None, None]
+    ref = torch.relu(y2 * bc(s2) + bc(b2) + yd * bc(sd) + bc(bd))
+    out = torch.empty(n, h, w, c, device=cuda)
+    t = [nhwc(y2).to(cuda), s2.to(cuda), b2.to(cuda), nhwc(yd).to(cuda), sd.to(cuda), bd.to(cuda)]
+    L.check(L.lib().uwm_op_residual(P(t[0]), P(t[1]), P(t[2]), P(t[3]), P(t[4]), P(t[5]), P(out), n * h * w, c, stream()))
+    torch.cuda.synchronize()
+    assert (nchw(out.cpu()) - ref).abs().max() < 1e-5
+    # max-pool backward through relu(bn(y)) with an added skip gradient
+    y = torch.randn(n, c, h, w, generator=g)
+    a = torch.relu(y * bc(s2) + bc(b2)).requires_grad_()
+    pooled = F.max_pool2d(a, 3, 2, 1)
+    go = torch.randn(pooled.shape, generator=g)
+    pooled.backward(go)
+    addend = torch.randn(n, h, w, c, generator=g)
+    yd_ = nhwc(y).to(cuda); tt = [s2.to(cuda), b2.to(cuda)]
+    s0 = src(yd_, tt[0], tt[1], relu=1)
+    po = torch.empty(n, h // 2, w // 2, c, device=cuda); idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.uint8, device=cuda)
+    L.check(L.lib().uwm_op_maxpool(C.byref(s0), n, P(po), P(idx), stream()))
+    gin = torch.empty(n, h, w, c, device=cuda)
+    gd, ad = nhwc(go).to(cuda), addend.to(cuda)
+    L.check(L.lib().uwm_op_maxpool_backward(P(gd), P(idx), P(ad), C.byref(s0), n, P(gin), stream()))
+    torch.cuda.synchronize()
+    refg = (a.grad.permute(0, 2, 3, 1) + addend) * (a.detach().permute(0, 2, 3, 1) > 0)
+    # positive near-ties may route to another tap on one side only (FMA rounding): tolerate a handful
+    bad = ((gin.cpu() - refg).abs() > 1e-5).float().mean()
+    assert bad < 1e-3, bad

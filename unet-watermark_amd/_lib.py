@@ -70,6 +70,10 @@ SIGNATURES = {
     "uwm_op_wgrad": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, I, I, P, I, P]),
     "uwm_op_pack_dgrad": (I, [P, I, I, I, I, P, I, I, P]),
     "uwm_op_maxpool": (I, [C.POINTER(uwm_src), I, P, P, P]),
+    "uwm_op_maxpool_backward": (I, [P, P, P, C.POINTER(uwm_src), I, P, P]),
+    "uwm_op_bn_backward": (I, [P, P, P, P, P, P, P, P, P, L, I, P]),
+    "uwm_op_upsplit": (I, [P, I, I, I, I, I, P, P, P, P, P, P]),
+    "uwm_op_residual": (I, [P, P, P, P, P, P, P, L, I, P]),
 }
 
 _lib = None

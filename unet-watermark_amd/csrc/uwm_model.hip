@@ -775,6 +775,34 @@ int uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, fl
   LCHK(launch_pack_dgrad(w, Cout, Kpad, ntaps, Cin, wd, KpadD, CoutP, (hipStream_t)stream));
   return 0;
 }
+int uwm_op_bn_backward(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
+                       double* scratch2c, float* dy, float* dgamma, float* dbeta, long long npix, int C, uwm_stream stream) {
+  if (!g || !y || !mean || !rstd || !gamma || !scratch2c || !dy || !dgamma || !dbeta || npix < 1) return fail("uwm_op_bn_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(scratch2c, 0, 2 * (size_t)C * sizeof(double), st));
+  LCHK(launch_bn_bwd_reduce(g, y, mean, rstd, scratch2c, scratch2c + C, (size_t)npix, C, st));
+  LCHK(launch_bn_bwd_apply(g, y, mean, rstd, gamma, scratch2c, scratch2c + C, dy, dgamma, dbeta, (size_t)npix, C, st));
+  return 0;
+}
+int uwm_op_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev, const float* pmask,
+                   const float* pscale, const float* pshift, float* gskip, uwm_stream stream) {
+  if (!dcat || !gprev) return fail("uwm_op_upsplit: null argument");
+  LCHK(launch_upsplit(dcat, N, H, W, C0, C1, gprev, pmask, pscale, pshift, gskip, (hipStream_t)stream));
+  return 0;
+}
+int uwm_op_residual(const float* y, const float* s2, const float* b2, const float* id, const float* sd, const float* bd,
+                    float* out, long long npix, int C, uwm_stream stream) {
+  if (!y || !s2 || !b2 || !id || !out) return fail("uwm_op_residual: null argument");
+  LCHK(launch_residual(y, s2, b2, id, sd, bd, out, (size_t)npix, C, (hipStream_t)stream));
+  return 0;
+}
+int uwm_op_maxpool_backward(const float* gout, const uint8_t* idx, const float* addend, const uwm_src* in, int N, float* gin,
+                            uwm_stream stream) {
+  if (!gout || !idx || !in || !gin) return fail("uwm_op_maxpool_backward: null argument");
+  Src s = to_src(in);
+  LCHK(launch_maxpool_bwd(gout, idx, addend, s, gin, N, (s.H - 1) / 2 + 1, (s.W - 1) / 2 + 1, (hipStream_t)stream));
+  return 0;
+}
 int uwm_op_maxpool(const uwm_src* in, int N, float* out, uint8_t* idx, uwm_stream stream) {
   if (!in || !out) return fail("uwm_op_maxpool: null argument");
   Src s = to_src(in);
