@@ -86,14 +86,17 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_ddp = bool(int(os.environ.get("UWM_FORCE_DDP", "0")))      # 1-rank RCCL group: exercises the DDP path on one GPU
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     torch.manual_seed(42)                                  # identical init on every rank (+ broadcast in Trainer)
     model = U.Unet(args.encoder, encoder_weights=None, in_channels=3, classes=1).to(dev)
     trainer = Trainer(model, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-4, weight_decay=1e-4,
-                      overlap_comm=not args.no_overlap)
+                      overlap_comm=not args.no_overlap, force_ddp=force_ddp)
     g = torch.Generator(device="cpu").manual_seed(42 + rank)      # rank-distinct synthetic data
     n, s = args.batch, args.size
     x = torch.randn(n, 3, s, s, generator=g).to(dev)
@@ -151,7 +154,7 @@ def main():
             "config": {"workload": f"Unet-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
                                    f"(BASELINE.json configs[{1 if world == 1 else 2}])",
                        "global_batch": world * n, "image": [s, s], "parallelism": f"dp{world}",
-                       "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if world > 1 else "none")},
+                       "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if (world > 1 or force_ddp) else "none")},
             "loss": round(loss_val, 6),
             "model_tflops": round(world * n * fwdbwd * args.steps / dt / 1e12, 2),
             "roofline": None, "kernels": kernels,
@@ -167,7 +170,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.encoder, s)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

@@ -322,3 +322,21 @@ def test_cli_train_on_synthetic_learns(cuda, tmp_path):
     from unet_watermark_amd.checkpoint import load_checkpoint
     ck = load_checkpoint(str(tmp_path / "best.pth"))
     assert "encoder.conv1.weight" in ck["model_state_dict"] and ck["config"]["MODEL"]["ENCODER_NAME"] == "resnet18"
+
+
+def test_bench_ddp_path_single_rank_rccl(cuda):
+    """The data-parallel step (RCCL all-reduce of 5 gradient buckets on a side stream, overlapped with the staged
+    backward) run through torch.distributed.run with ONE rank: same loss as the plain single-GPU step."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "3", "--warmup", "1", "--batch", "2", "--size", "128", "--encoder", "resnet18", "--no-cpu-baseline"]
+    env = dict(os.environ, UWM_FORCE_DDP="1")
+    ddp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert ddp.returncode == 0, ddp.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(ddp.stdout.strip().splitlines()[-1]); b = json.loads(one.stdout.strip().splitlines()[-1])
+    assert a["config"]["grad_allreduce"].startswith("rccl") and b["config"]["grad_allreduce"] == "none"
+    assert abs(a["loss"] - b["loss"]) < 1e-4 and a["value"] > 0

@@ -28,17 +28,19 @@ class GradReducer:
     grad_scale.  Works on CPU tensors with the gloo backend (tests) — then without streams.
     """
 
-    def __init__(self, flat_grads: torch.Tensor, buckets: Sequence[Tuple[int, int]], group=None):
+    def __init__(self, flat_grads: torch.Tensor, buckets: Sequence[Tuple[int, int]], group=None, force: bool = False):
         self.flat = flat_grads
         self.buckets = [(int(b), int(e)) for b, e in buckets if e > b]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # force: run the collectives even in a 1-rank group (exercises the RCCL + side-stream path on one GPU)
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.on_gpu = flat_grads.device.type == "cuda"
-        self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if (self.on_gpu and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream(device=flat_grads.device) if (self.on_gpu and self.active) else None
         self._works = []
 
     def reduce(self, k: int):
-        if self.world == 1:
+        if not self.active:
             return
         b, e = self.buckets[k]
         view = self.flat[b:e]
@@ -122,13 +124,15 @@ class Trainer:
 
     def __init__(self, model, w_dice: float = 1.0, w_bce: float = 0.0, smooth: float = 1e-5, eps: float = 1e-7,
                  lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0,
-                 group=None, overlap_comm: bool = True):
+                 group=None, overlap_comm: bool = True, force_ddp: bool = False):
         self.model = model
         self.w_dice, self.w_bce, self.smooth, self.eps = float(w_dice), float(w_bce), float(smooth), float(eps)
         self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.overlap = overlap_comm
+        self.ddp = self.world > 1 or (force_ddp and dist.is_available() and dist.is_initialized())
+        self._force = force_ddp
         self._reducer = None
         self._dl = None
         self._scratch = None
@@ -162,9 +166,9 @@ class Trainer:
                                  C.c_void_p(self._scratch.data_ptr()), C.c_void_p(self._loss.data_ptr()),
                                  C.c_void_p(self._dl.data_ptr()), m._cp, 1.0, st))
         nst = len(m.stages)
-        if self.world > 1:
+        if self.ddp:
             if self._reducer is None or self._reducer.flat.data_ptr() != m.flat_grads().data_ptr():
-                self._reducer = GradReducer(m.flat_grads(), m.stages, self.group)
+                self._reducer = GradReducer(m.flat_grads(), m.stages, self.group, force=self._force)
             if self.overlap:
                 for k in range(nst):
                     m._backward_raw(self._dl, k, k + 1)
