@@ -24,14 +24,14 @@ constexpr int kPUnits = kPP * 8;                                                
 constexpr int kPRounds = (kPUnits + 255) / 256;                                 // 6
 
 template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, BN >= 128 ? 2 : 3) void conv_patch_kernel(const ConvArgs a) {
   constexpr int MI = kTH / WM;            // one MFMA M-tile = one 16-pixel row of the block
   constexpr int NI = BN / WN / 16;
   constexpr int WR = (BN + 31) / 32;
   static_assert(WM * WN == 4 && MI >= 1 && NI >= 1, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const Ps = smem;                        // [2][180][32]
-  float* const Ws = smem + 2 * kPP * 32;         // [2][BN][32]
+  float* const Ps = smem;                        // [180][32]   (single-buffered)
+  float* const Ws = smem + kPP * 32;             // [2][BN][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -112,21 +112,20 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvArgs a) {
   };
 
   const int nchunk = a.Ctot >> 5;
-  const int nsteps = nchunk * 9;
   // prologue: whole patch of chunk 0 (all rounds in flight together) + weights of step 0
+  f4 qv[kPRounds], qsc, qsh; int qpos[kPRounds]; unsigned qact = 0, qhas = 0; int qrelu = 0;
   {
-    f4 qv[kPRounds], qsc[kPRounds], qsh[kPRounds]; int qpos[kPRounds]; unsigned qact = 0, qhas = 0, qrelu = 0;
 #pragma unroll
     for (int rd = 0; rd < kPRounds; ++rd) {
       patch_load(0, rd, true);
-      qv[rd] = pv; qsc[rd] = psc; qsh[rd] = psh; qpos[rd] = ppos;
-      qact |= (pact ? 1u : 0u) << rd; qhas |= (phas ? 1u : 0u) << rd; qrelu |= (prelu ? 1u : 0u) << rd;
+      qv[rd] = pv; qpos[rd] = ppos;
+      qact |= (pact ? 1u : 0u) << rd; qhas |= (phas ? 1u : 0u) << rd;
     }
+    qsc = psc; qsh = psh; qrelu = prelu;          // channel unit (tid & 7) is the same for every round
     w_load(0, 0);
 #pragma unroll
     for (int rd = 0; rd < kPRounds; ++rd) {
-      pv = qv[rd]; psc = qsc[rd]; psh = qsh[rd]; ppos = qpos[rd];
-      pact = (qact >> rd) & 1u; phas = (qhas >> rd) & 1u; prelu = (qrelu >> rd) & 1u;
+      pv = qv[rd]; ppos = qpos[rd]; pact = (qact >> rd) & 1u; phas = (qhas >> rd) & 1u;
       patch_store(0);
     }
     w_store(0);
@@ -134,28 +133,22 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvArgs a) {
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
-  int cc = 0, tap = 0;
-  for (int step = 0; step < nsteps; ++step) {
-    const int ncc = (tap == 8) ? cc + 1 : cc, ntap = (tap == 8) ? 0 : tap + 1;
-    // prefetch is unconditional (clamped / lane-masked) so the loop body is ONE basic block and the
-    // loaded registers are not loop-carried phis (hipcc otherwise copies them right behind the loads,
-    // i.e. waits vmcnt(0) at the top of the MFMA block)
-    const bool more = step + 1 < nsteps;
-    w_load(more ? ncc : 0, more ? ntap : 0);
-    const bool ppiece = (tap < kPRounds) && (cc + 1 < nchunk);
-    patch_load(ppiece ? cc + 1 : 0, ppiece ? tap : 0, ppiece);
-
+  // The patch is SINGLE-buffered (39 KB of LDS per workgroup for BN=64 -> 4 workgroups per CU instead of 2):
+  // the six pieces of the next chunk are fetched into registers during taps 3..8 and written after the
+  // chunk's last barrier.  The nine taps are unrolled, so tap offsets and register indices are static.
+  auto step_body = [&](int cc, int tap, bool next_chunk) {
+    const bool more = next_chunk || tap < 8;
+    w_load(tap == 8 ? (next_chunk ? cc + 1 : 0) : cc, tap == 8 ? 0 : (more ? tap + 1 : 0));
     const int r = tap / 3, s = tap - r * 3;
     const int rr = mirror ? 2 - r : r, ss = mirror ? 2 - s : s;
-    const float* ps = Ps + (cc & 1) * kPP * 32;
-    const float* ws = Ws + (step & 1) * BN * 32;
+    const float* ws = Ws + ((cc + tap) & 1) * BN * 32;       // step = 9*cc + tap, 9 is odd
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
       f4 xf[MI], wf[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int pp = (wm * MI + i + rr) * kPW + lrow + ss;
-        xf[i] = *(const f4*)(ps + pp * 32 + (((k16 * 4 + lq) ^ ((pp >> 1) & 7)) << 2));
+        xf[i] = *(const f4*)(Ps + pp * 32 + (((k16 * 4 + lq) ^ ((pp >> 1) & 7)) << 2));
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -170,13 +163,38 @@ __global__ __launch_bounds__(256, 2) void conv_patch_kernel(const ConvArgs a) {
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xf[i][e], acc[i][j], 0, 0, 0);
     }
-    // keep every consumer of this step's global loads BELOW the MFMA block: without the fence hipcc
-    // hoists the BatchNorm-transform math above the MFMAs and waits vmcnt(0) right after issuing the loads
+    // keep every consumer of this step's global loads BELOW the MFMA block (hipcc otherwise hoists the
+    // BatchNorm-transform math above the MFMAs and waits vmcnt(0) right after issuing the loads)
     __builtin_amdgcn_sched_barrier(0);
-    w_store((step + 1) & 1);
-    patch_store((cc + 1) & 1);
+    w_store((cc + tap + 1) & 1);
     __syncthreads();
-    cc = ncc; tap = ntap;
+  };
+
+  for (int cc = 0; cc < nchunk; ++cc) {
+    const bool next_chunk = cc + 1 < nchunk;
+#pragma unroll 1
+    for (int tap = 0; tap < 6; ++tap) step_body(cc, tap, next_chunk);
+    // all six pieces of the NEXT chunk's patch are requested here, as straight-line code into named registers;
+    // they are consumed after tap 8's barrier, i.e. three steps (~6k cycles) later
+    qact = 0; qhas = 0;
+#pragma unroll
+    for (int rd = 0; rd < kPRounds; ++rd) {
+      patch_load(next_chunk ? cc + 1 : 0, rd, next_chunk);
+      qv[rd] = pv; qpos[rd] = ppos;
+      qact |= (pact ? 1u : 0u) << rd; qhas |= (phas ? 1u : 0u) << rd;
+    }
+    qsc = psc; qsh = psh; qrelu = prelu;
+#pragma unroll 1
+    for (int tap = 6; tap < 9; ++tap) step_body(cc, tap, next_chunk);
+    if (next_chunk) {                               // every wave has passed the barrier of tap 8: patch(cc) is dead
+#pragma unroll
+      for (int rd = 0; rd < kPRounds; ++rd) {
+        pv = qv[rd]; ppos = qpos[rd]; psc = qsc; psh = qsh; prelu = qrelu;
+        pact = (qact >> rd) & 1u; phas = (qhas >> rd) & 1u;
+        patch_store(0);
+      }
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue (same contract as conv_igemm_kernel) ----------------
@@ -247,7 +265,7 @@ template <int BN, int WM, int WN>
 static hipError_t launch_p(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesN = (a.Cout + BN - 1) / BN;
   const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
-  const size_t lds = (size_t)(2 * kPP * 32 + 2 * BN * 32) * sizeof(float);
+  const size_t lds = (size_t)(kPP * 32 + 2 * BN * 32) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_patch_kernel<BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
