@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--encoder", default="resnet34")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
+    ap.add_argument("--serial-steps", type=int, default=3,
+                    help="extra UNTIMED steps after the timed region with the wgrad side stream off, to report the "
+                         "dominant kernel's un-overlapped launch time next to the overlapped one (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -126,6 +129,19 @@ def main():
     prof = (C.c_double * (64 * 3))()
     ncls = L.lib().uwm_prof_collect(prof, 64)
     loss_val = float(loss[0].item())
+    # un-overlapped kernel times (NOT part of `value`): same step with the wgrad side stream switched off
+    prof_s = None
+    if args.serial_steps > 0 and rank == 0 and world == 1:
+        L.lib().uwm_set_side_stream(model._h, 0)
+        trainer.step(x, t); torch.cuda.synchronize(dev)
+        L.lib().uwm_prof_enable(1)
+        for _ in range(args.serial_steps):
+            trainer.step(x, t)
+        torch.cuda.synchronize(dev)
+        L.lib().uwm_prof_enable(0)
+        prof_s = (C.c_double * (64 * 3))()
+        L.lib().uwm_prof_collect(prof_s, 64)
+        L.lib().uwm_set_side_stream(model._h, 1)
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -160,10 +176,21 @@ def main():
             "roofline": None, "kernels": kernels,
         }
         if dom:
+            serial = None
+            if prof_s is not None:
+                for c in range(ncls):
+                    if L.lib().uwm_prof_class_name(c).decode() == dom["kernel"] and prof_s[c * 3] > 0:
+                        cnt, ms, fl = prof_s[c * 3], prof_s[c * 3 + 1], prof_s[c * 3 + 2]
+                        serial = {"avg_launch_us": round(1e3 * ms / cnt, 2), "achieved": round(fl / ms / 1e9, 2),
+                                  "frac": round(fl / ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                  "note": f"{args.serial_steps} extra untimed steps with the wgrad side stream off"}
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                                "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(dom["tflops"] / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
                                "avg_launch_us": dom["avg_us"],
+                               "note": "launch durations in the timed region include co-residency with kernels of the "
+                                       "other stream (wgrad side stream); `unoverlapped` is the same kernel alone",
+                               "unoverlapped": serial,
                                "all_conv_kernels": {"tflops": round(tot_fl / tot_ms / 1e9, 2),
                                                     "frac": round(tot_fl / tot_ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
                                                     "share_of_step": round(tot_ms / args.steps / ms_step, 4)}}

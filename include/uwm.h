@@ -116,6 +116,10 @@ int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float l
               float eps, float weight_decay, long long step, float grad_scale, uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
 
+/* Weight-gradient kernels run on an internal side stream (forked from / joined to the caller's stream with events,
+ * per backward stage) so they overlap the dgrad chain; this switches that off/on at run time (default on). */
+int  uwm_set_side_stream(uwm_handle h, int on);
+
 /* Optional HIP-event profiler: while enabled every conv / wgrad launch is bracketed by a hipEvent pair
  * recorded on its launch stream.  uwm_prof_collect waits for the events and returns, per kernel class,
  * {launches, total ms, total algorithmic FLOPs} in out[class*3 + 0..2]; returns the number of classes. */

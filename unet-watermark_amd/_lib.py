@@ -61,6 +61,7 @@ SIGNATURES = {
     "uwm_threshold": (I, [P, I, L, F, I, P, P]),
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
     "uwm_scale": (I, [P, L, F, P]),
+    "uwm_set_side_stream": (I, [P, I]),
     "uwm_prof_enable": (I, [I]),
     "uwm_prof_collect": (I, [C.POINTER(C.c_double), I]),
     "uwm_prof_class_name": (C.c_char_p, [I]),

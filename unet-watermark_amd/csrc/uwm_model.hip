@@ -656,6 +656,12 @@ int uwm_scale(float* p, long long n, float s, uwm_stream stream) {
   return 0;
 }
 
+// ---- run-time switch for the internal weight-gradient side stream (default on; UWM_SIDE_STREAM=0 disables it)
+int uwm_set_side_stream(uwm_handle h, int on) {
+  if (!h) return fail("uwm_set_side_stream: null handle");
+  h->use_side = on != 0; return 0;
+}
+
 // ---- HIP-event profiler (bench.py's roofline leg)
 int uwm_prof_enable(int on) { prof_enable(on != 0); return 0; }
 int uwm_prof_collect(double* out, int max_classes) {
