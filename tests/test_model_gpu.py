@@ -340,3 +340,45 @@ def test_bench_ddp_path_single_rank_rccl(cuda):
     a = json.loads(ddp.stdout.strip().splitlines()[-1]); b = json.loads(one.stdout.strip().splitlines()[-1])
     assert a["config"]["grad_allreduce"].startswith("rccl") and b["config"]["grad_allreduce"] == "none"
     assert abs(a["loss"] - b["loss"]) < 1e-4 and a["value"] > 0
+
+
+@pytest.mark.parametrize("enc,n,h,w,train", [
+    ("resnet18", 3, 32, 64, False),     # minimum height: layer4 is 1x2 pixels (igemm fallbacks everywhere)
+    ("resnet18", 1, 32, 32, False),     # 1x1 bottleneck, batch 1
+    ("resnet18", 5, 96, 160, True),     # odd batch, W/32 = 5
+    ("resnet34", 1, 224, 224, True),    # H/32 = 7: partial 8x16 tiles on every level
+    ("resnet18", 2, 64, 416, True),     # wide strip
+])
+def test_shape_sweep_forward_and_gradient_direction(cuda, enc, n, h, w, train):
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    m, ref = _pair(enc, dev=cuda, seed=5)
+    x, t = O.synthetic_batch(n, h, w, seed=21)
+    if not train:
+        m.eval(); ref.eval()
+        with torch.no_grad():
+            assert (m(x.to(cuda)).cpu() - ref(x)).abs().max() < LOGIT_TOL
+        return
+    m.train(); ref.train()
+    out_ref = ref(x); O.DiceLoss(smooth=1e-5)(out_ref, t.unsqueeze(1)).backward()
+    out = m(x.to(cuda)); U.DiceLoss(smooth=1e-5)(out, t.unsqueeze(1).to(cuda)).backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    _grad_check(m, ref, l2_rel=6e-2, cos_min=0.998)
+
+
+def test_in_channels_1_and_custom_decoder(cuda):
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    kw = dict(in_channels=1, decoder_channels=(128, 64, 32, 16, 8))
+    m, ref = _pair("resnet18", dev=cuda, seed=9, **kw)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 1, 128, 96, generator=g)
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert (m(x.to(cuda)).cpu() - ref(x)).abs().max() < LOGIT_TOL
+    m.train(); ref.train()
+    t = (torch.rand(2, 1, 128, 96, generator=g) > 0.8).long()
+    out_ref = ref(x); O.DiceLoss(smooth=1e-5)(out_ref, t).backward()
+    out = m(x.to(cuda)); U.DiceLoss(smooth=1e-5)(out, t.to(cuda)).backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    _grad_check(m, ref, l2_rel=6e-2, cos_min=0.998)
