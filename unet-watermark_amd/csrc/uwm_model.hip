@@ -71,8 +71,9 @@ struct uwm_model {
   // weight-gradient kernels run on an internal side stream, forked from / joined to the caller's stream
   // with events (capturable fork-join; no host synchronisation)
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
   int use_side = 1;
+  bool packed_in_fwd = false;         // dgrad weight repacks were enqueued on the side stream by the last forward
 };
 
 static int add_bn(uwm_model* m, const std::string& name, int C, int stage) {
@@ -364,6 +365,20 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
   const Plan& p = m->plan;
   Ctx c{m, ws, st, N};
   if (training) HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
+  m->packed_in_fwd = false;
+  if (training && m->use_side && m->side && m->grads) {
+    // the [Cin][tap][Cout] weight repacks the backward's dgrads need depend only on the parameters: enqueue them
+    // on the side stream now (after everything already on the caller's stream, i.e. after the last optimizer step)
+    // so they cost nothing; uwm_backward waits for ev_pack
+    HIPCHK(hipEventRecord(m->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    for (auto& cv : m->convs)
+      if (cv.dgrad)
+        LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
+                               cv.CoutP, m->side));
+    HIPCHK(hipEventRecord(m->ev_pack, m->side));
+    m->packed_in_fwd = true;
+  }
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
   // eval: all BN scale/shift come from running stats and are known up front
   if (!training) for (size_t i = 0; i < m->bns.size(); ++i) LCHK(run_bn_finalize(c, (int)i, 1, 0));
@@ -442,12 +457,16 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
 
   if (sb <= 0 && se > 0) {
     HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
-    // zero dgamma/dbeta halves of every BN's double scratch
-    for (auto& b : m->bns) HIPCHK(hipMemsetAsync(c.D(b.d_off) + 2 * b.C, 0, 2 * (size_t)b.C * sizeof(double), st));
-    for (auto& cv : m->convs)
-      if (cv.dgrad)
-        LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
-                               cv.CoutP, st));
+    // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
+    HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
+    if (m->packed_in_fwd) {
+      HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
+    } else {
+      for (auto& cv : m->convs)
+        if (cv.dgrad)
+          LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
+                                 cv.CoutP, st));
+    }
     // ---------------- head
     const ConvL& hd = m->convs[m->head];
     const DecL& dl4 = m->dec.back();
@@ -550,6 +569,7 @@ void uwm_destroy(uwm_handle h) {
   if (!h) return;
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
@@ -575,7 +595,8 @@ int uwm_bind(uwm_handle h, float* params, float* grads, float* buffers) {
   if (h->use_side && !h->side) {        // created lazily on the device the arenas live on (current device)
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; (void)hipGetLastError(); }
     else if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(h->side); h->side = nullptr; (void)hipGetLastError();
     }
   }
