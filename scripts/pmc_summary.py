@@ -1,0 +1,33 @@
+"""Digest rocprofv3 --pmc passes of `bench.py` (FETCH_SIZE, WRITE_SIZE, MFMA-busy) into profiles/:
+   usage: scripts/pmc_summary.py <fetch_dir> <write_dir> <mfma_dir> <tag>
+   writes profiles/<tag>_pmc_summary.json and profiles/pmc_traffic.json (read by bench.py for roofline.traffic)."""
+import collections, csv, glob, json, re, sys
+fd, wd, md, tag = sys.argv[1:5]
+def norm(k):
+    k = k.split("(")[0].replace("void uwm::", "").replace("uwm::", "")
+    return re.sub(r"\s+", "", k)
+def load(d):
+    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = norm(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in n.items()}
+fa, fn = load(fd); wa, wn = load(wd); ma, mn = load(md)
+tr = glob.glob(f"{md}/*/*_kernel_trace.csv")[0]
+dur = collections.defaultdict(float); cnt = collections.Counter()
+for r in csv.DictReader(open(tr)):
+    k = norm(r["Kernel_Name"]); dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[k] += 1
+rows, traffic = [], {}
+alias = {"wgrad_patch_kernel<64,32>": "wgrad_patch_kernel<64>", "wgrad_patch_kernel<32,32>": "wgrad_patch_kernel<32>",
+         "wgrad_patch_kernel<16,32>": "wgrad_patch_kernel<16>"}
+for k in sorted(dur, key=lambda k: -dur[k])[:16]:
+    fe = fa[k].get("FETCH_SIZE", 0) / max(1, fn.get(k, 1)) * 1024; wr = wa[k].get("WRITE_SIZE", 0) / max(1, wn.get(k, 1)) * 1024
+    gui = ma[k].get("GRBM_GUI_ACTIVE", 0); busy = ma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+    rows.append(dict(kernel=k, launches=cnt[k], avg_us=round(dur[k] / cnt[k], 1), fetch_bytes_raw=int(fe), fetch_bytes_x2=int(2 * fe),
+                     write_bytes=int(wr), mfma_busy_frac=round(busy / (gui / 8 * 1024), 3) if gui else None,
+                     clock_GHz=round(gui / 8 / (dur[k] * 1e3), 2) if dur[k] else None))
+    traffic[alias.get(k, k)] = {"hbm_bytes_per_launch": int(2 * fe + wr)}
+json.dump(rows, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+json.dump({"source": f"profiles/{tag}_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; FETCH_SIZE x2 (gfx950), per launch",
+           "kernels": traffic}, open("profiles/pmc_traffic.json", "w"), indent=1)
+for r in rows[:8]: print(r)
