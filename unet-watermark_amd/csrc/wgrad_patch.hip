@@ -137,9 +137,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
   }
   __syncthreads();
 
+  const int dbg = a.force_igemm >> 8;                        // timing-only ablation bits (results are garbage when set)
   for (int t = t0; t < t1; ++t) {
     const int cur = (t - t0) & 1;
-    tile_load(t + 1 < t1 ? t + 1 : t, t + 1 < t1);          // unconditional, lane-masked prefetch
+    tile_load(t + 1 < t1 ? t + 1 : t, (t + 1 < t1) && !(dbg & 1));          // unconditional, lane-masked prefetch
     const float* ys = Ys + cur * 128 * TA;
     const float* ps = Ps + cur * kPP * CW;
     // Fragment reads run ONE k4-step ahead of the MFMAs (explicit register double buffer + scheduling
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
 #pragma unroll
     for (int kk = 0; kk < K4W; ++kk) {
       const int cb = kk & 1;
-      if (kk + 1 < K4W) frag_read(kk + 1, cb ^ 1);
+      if (kk + 1 < K4W && !(dbg & 8)) frag_read(kk + 1, cb ^ 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
@@ -183,9 +184,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);   // consumers of the prefetch stay below the MFMA block
-    tile_store(cur ^ 1);
-    __syncthreads();
+    if (!(dbg & 2)) tile_store(cur ^ 1);
+    if (!(dbg & 4)) __syncthreads();
   }
+  if (dbg & 16) return;
 
   // ---- combine the 8 waves' partial tiles in LDS (ds_add_f32), then ONE coalesced pass of global atomics
   // tile layout in LDS: [TA co][9 taps][32 c]   (the staging buffers are dead after the last barrier)
@@ -202,7 +204,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_patch_kernel(const WgradArgs a) 
         if (wk == 0) Rt[co * 9 * CW + t * CW + NJ * li + j] = acc[t][j][e];   // D column li -> channel NJ*li + j
       }
   __syncthreads();
-  if (wk != 0) {
+  if (WK == 2) {
+    // exactly one other wave owns the same (co, tap, c) elements: plain read-add-write, no LDS atomics
+    if (wk == 1) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = wa * 16 + lq * 4 + e;
+            Rt[co * 9 * CW + t * CW + NJ * li + j] += acc[t][j][e];
+          }
+    }
+  } else if (wk != 0) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
