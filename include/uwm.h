@@ -114,7 +114,16 @@ int  uwm_threshold(const float* logits, int ld, long long npix, float threshold,
 /* torch.optim.Adam (coupled weight decay) over a flat range; step = 1-based step count */
 int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
               float eps, float weight_decay, long long step, float grad_scale, uwm_stream stream);
+/* same, preceded by global-norm gradient clipping (torch.nn.utils.clip_grad_norm_(params, max_norm)): the norm of
+ * grad_scale*g over the whole range is reduced on the device (scratch: >= 8 bytes) and folded into the update */
+int  uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, long long step, float grad_scale, float max_norm, void* scratch,
+                   uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
+/* predict.py:620-625 on the device: bilinear resize (cv2.INTER_LINEAR convention) of each image's logit plane
+ * [N][h][w] (element stride ld) to [N][H][W], then (v > threshold) ? 255 : 0.  mask and/or resized may be NULL. */
+int  uwm_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float threshold,
+                          int apply_sigmoid, uint8_t* mask, float* resized, uwm_stream stream);
 
 /* Weight-gradient kernels run on an internal side stream (forked from / joined to the caller's stream with events,
  * per backward stage) so they overlap the dgrad chain; this switches that off/on at run time (default on). */

@@ -382,3 +382,34 @@ def test_in_channels_1_and_custom_decoder(cuda):
     out = m(x.to(cuda)); U.DiceLoss(smooth=1e-5)(out, t.to(cuda)).backward()
     assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
     _grad_check(m, ref, l2_rel=6e-2, cos_min=0.998)
+
+
+def test_resize_threshold_matches_bilinear_reference(cuda):
+    """predict.py:620-625: resize raw logits to the original image size (bilinear) then threshold."""
+    import unet_watermark_amd as U
+    g = torch.Generator().manual_seed(6)
+    logits = torch.randn(3, 1, 64, 96, generator=g) * 2
+    for size in ((150, 201), (64, 96), (33, 50), (480, 640)):
+        ref = torch.nn.functional.interpolate(logits, size=size, mode="bilinear", align_corners=False)
+        mask, rs = U.resize_threshold(logits.to(cuda), size, 0.5, return_resized=True)
+        assert (rs.cpu() - ref[:, 0]).abs().max() < 2e-5
+        refm = ((ref[:, 0] > 0.5).to(torch.uint8) * 255)
+        assert (mask.cpu() != refm).float().mean() < 1e-4          # only pixels within rounding of the threshold may differ
+
+
+def test_adam_with_global_norm_clipping(cuda):
+    import ctypes as C
+    from unet_watermark_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    n = 50001
+    p0 = torch.randn(n, generator=g); gr = torch.randn(n, generator=g) * 3
+    pr = p0.clone().requires_grad_(); pr.grad = gr.clone()
+    torch.nn.utils.clip_grad_norm_([pr], 1.0)
+    opt = torch.optim.Adam([pr], lr=1e-2, eps=1e-3); opt.step()
+    p = p0.to(cuda); gd = gr.to(cuda); mm = torch.zeros_like(p); vv = torch.zeros_like(p)
+    scr = torch.zeros(2, dtype=torch.float64, device=cuda)
+    L.check(L.lib().uwm_adam_clip(C.c_void_p(p.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(mm.data_ptr()),
+                                  C.c_void_p(vv.data_ptr()), n, 1e-2, 0.9, 0.999, 1e-3, 0.0, 1, 1.0, 1.0,
+                                  C.c_void_p(scr.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert abs(float(scr[0]) ** 0.5 - float(gr.norm())) < 1e-3 * float(gr.norm())
+    assert (p.cpu() - pr.detach()).abs().max() < 2e-6

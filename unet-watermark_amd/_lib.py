@@ -60,7 +60,9 @@ SIGNATURES = {
     "uwm_stats": (I, [P, I, P, I, I, L, F, I, P, P]),
     "uwm_threshold": (I, [P, I, L, F, I, P, P]),
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
+    "uwm_adam_clip": (I, [P, P, P, P, L, F, F, F, F, F, L, F, F, P, P]),
     "uwm_scale": (I, [P, L, F, P]),
+    "uwm_resize_threshold": (I, [P, I, I, I, I, I, I, F, I, P, P, P]),
     "uwm_set_side_stream": (I, [P, I]),
     "uwm_prof_enable": (I, [I]),
     "uwm_prof_collect": (I, [C.POINTER(C.c_double), I]),

@@ -97,7 +97,8 @@ def train_command(args):
     model = create_model_from_config(cfg).to(device)
     wd, wb = _loss_weights(cfg)
     trainer = Trainer(model, w_dice=wd, w_bce=wb, smooth=float(cfg.LOSS.SMOOTH), lr=float(cfg.TRAIN.LR),
-                      weight_decay=float(cfg.TRAIN.WEIGHT_DECAY))
+                      weight_decay=float(cfg.TRAIN.WEIGHT_DECAY),
+                      max_grad_norm=(float(cfg.TRAIN.GRADIENT_CLIP) if args.grad_clip else None))
     criterion = get_loss_function(cfg)
     start_epoch, best = 0, float("inf")
     if args.resume:
@@ -166,10 +167,11 @@ def predict_command(args):
         chunk = files[i:i + bs]
         ims = [Image.open(os.path.join(args.input, f)).convert("RGB") for f in chunk]
         arr = np.stack([np.asarray(im.resize((s, s), Image.BILINEAR), dtype=np.uint8) for im in ims])
-        masks = pred.predict_mask(pred.preprocess(torch.from_numpy(arr)), apply_sigmoid=args.sigmoid,
-                                  use_graph=len(chunk) == bs).cpu().numpy()
-        for f, im, m in zip(chunk, ims, masks):
-            Image.fromarray(m).resize(im.size, Image.NEAREST).save(os.path.join(args.output, os.path.splitext(f)[0] + "_mask.png"))
+        logits = pred.logits(pred.preprocess(torch.from_numpy(arr)), use_graph=len(chunk) == bs)
+        from .metrics import resize_threshold
+        for k, (f, im) in enumerate(zip(chunk, ims)):          # bilinear resize of the raw logits to the original size, then threshold
+            m = resize_threshold(logits[k:k + 1], (im.size[1], im.size[0]), pred.threshold, args.sigmoid)[0].cpu().numpy()
+            Image.fromarray(m).save(os.path.join(args.output, os.path.splitext(f)[0] + "_mask.png"))
     print(f"wrote {len(files)} masks to {args.output}")
 
 
@@ -189,6 +191,7 @@ def main(argv=None):
     tp.add_argument("--encoder", type=str); tp.add_argument("--img-size", type=int)
     tp.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of DATA.ROOT_DIR")
     tp.add_argument("--workers", type=int, default=2)
+    tp.add_argument("--grad-clip", action="store_true", help="honour TRAIN.GRADIENT_CLIP (the reference defines but never applies it)")
     pp = sub.add_parser("predict")
     pp.add_argument("--input", type=str, required=True); pp.add_argument("--output", type=str, required=True)
     pp.add_argument("--model", type=str, required=True); pp.add_argument("--config", type=str, default=None)

@@ -354,7 +354,11 @@ hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double*
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, coupled L2)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             size_t n4, size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
-                            float gscale) {
+                            float gscale, const double* sumsq, float max_norm) {
+  if (sumsq) {   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+    const float tn = (float)sqrt(*sumsq) * gscale;
+    gscale *= fminf(1.f, max_norm / (tn + 1e-6f));
+  }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t o = i * 4;
     if (o + 4 <= n) {
@@ -378,10 +382,34 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-                       float wd, float bc1, float bc2, float gscale, hipStream_t st) {
+                       float wd, float bc1, float bc2, float gscale, hipStream_t st, const double* sumsq, float max_norm) {
   const size_t n4 = (n + 3) / 4;
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, p, g, m, v, n4, n, lr, b1, b2, eps, wd, bc1,
-                     sqrtf(bc2), gscale);
+                     sqrtf(bc2), gscale, sumsq, max_norm);
+  return hipGetLastError();
+}
+
+// sum of squares of a flat range (global gradient norm), fp64 across workgroups
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, size_t n, double* out) {
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = i * 4;
+    if (o + 4 <= n) { const f4 v = *(const f4*)(g + o); acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    else for (size_t j = o; j < n; ++j) acc += g[j] * g[j];
+  }
+  double d = (double)acc;
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+hipError_t launch_sumsq(const float* g, size_t n, double* out, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+  if (e != hipSuccess) return e;
+  const size_t n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks(n4, 1024)), dim3(256), 0, st, g, n4, n, out);
   return hipGetLastError();
 }
 

@@ -170,4 +170,35 @@ hipError_t launch_threshold(const float* logits, int ld, size_t npix, float thr,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- bilinear resize (cv2.INTER_LINEAR / torch
+// align_corners=False: src = (dst + 0.5) * in/out - 0.5, edge-clamped) of one logit plane per image + threshold
+__global__ void resize_threshold_kernel(const float* __restrict__ logits, int ld, int h, int w, int H, int W, float thr,
+                                        int apply_sigmoid, uint8_t* __restrict__ out, float* __restrict__ out_f, size_t total) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W); size_t r = i / W; const int Y = (int)(r % H); const int n = (int)(r / H);
+    float fy = ((float)Y + 0.5f) * sy - 0.5f, fx = ((float)X + 0.5f) * sx - 0.5f;
+    fy = fmaxf(fy, 0.f); fx = fmaxf(fx, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = min(y0, h - 1); x0 = min(x0, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float* b = logits + (size_t)n * h * w * ld;
+    const float v00 = b[((size_t)y0 * w + x0) * ld], v01 = b[((size_t)y0 * w + x1) * ld];
+    const float v10 = b[((size_t)y1 * w + x0) * ld], v11 = b[((size_t)y1 * w + x1) * ld];
+    float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+    if (apply_sigmoid) v = 1.f / (1.f + expf(-v));
+    if (out_f) out_f[i] = v;
+    if (out) out[i] = v > thr ? 255 : 0;
+  }
+}
+hipError_t launch_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float thr, int apply_sigmoid,
+                                   uint8_t* out, float* out_f, hipStream_t st) {
+  const size_t total = (size_t)N * H * W;
+  size_t nb = (total + 1023) / 1024; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(resize_threshold_kernel, dim3((unsigned)nb), dim3(256), 0, st, logits, ld, h, w, H, W, thr, apply_sigmoid, out,
+                     out_f, total);
+  return hipGetLastError();
+}
+
 }  // namespace uwm

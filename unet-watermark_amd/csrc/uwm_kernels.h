@@ -108,7 +108,11 @@ hipError_t launch_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int 
                              int CoutP, hipStream_t st);
 hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double* scratch, hipStream_t st);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
-                       float eps, float wd, float bc1, float bc2, float gscale, hipStream_t st);
+                       float eps, float wd, float bc1, float bc2, float gscale, hipStream_t st,
+                       const double* sumsq = nullptr, float max_norm = 0.f);
+hipError_t launch_sumsq(const float* g, size_t n, double* out, hipStream_t st);
+hipError_t launch_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float thr,
+                                   int apply_sigmoid, uint8_t* out, float* out_f, hipStream_t st);
 hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st);
 
 // loss / metrics (loss.hip)

@@ -671,6 +671,20 @@ int uwm_adam(float* p, const float* g, float* m, float* v, long long n, float lr
   LCHK(launch_adam(p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream));
   return 0;
 }
+int uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                  long long step, float gscale, float max_norm, void* scratch, uwm_stream stream) {
+  if (!p || !g || !m || !v || !scratch || n < 1 || step < 1 || max_norm <= 0.f) return fail("uwm_adam_clip: bad argument");
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  LCHK(launch_sumsq(g, (size_t)n, (double*)scratch, (hipStream_t)stream));
+  LCHK(launch_adam(p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream, (const double*)scratch, max_norm));
+  return 0;
+}
+int uwm_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float threshold, int apply_sigmoid,
+                         uint8_t* mask, float* resized, uwm_stream stream) {
+  if (!logits || (!mask && !resized) || N < 1 || h < 1 || w < 1 || H < 1 || W < 1 || ld < 1) return fail("uwm_resize_threshold: bad argument");
+  LCHK(launch_resize_threshold(logits, ld, N, h, w, H, W, threshold, apply_sigmoid, mask, resized, (hipStream_t)stream));
+  return 0;
+}
 int uwm_scale(float* p, long long n, float s, uwm_stream stream) {
   if (!p || n < 1) return fail("uwm_scale: bad argument");
   LCHK(launch_scale(p, (size_t)n, s, (hipStream_t)stream));

@@ -64,3 +64,19 @@ def threshold_mask(logits: torch.Tensor, threshold: float = 0.5, apply_sigmoid: 
     L.check(L.lib().uwm_threshold(C.c_void_p(xp), ld, n * h * w, float(threshold), int(apply_sigmoid),
                                   C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr(x.device))))
     return out
+
+
+def resize_threshold(logits: torch.Tensor, size, threshold: float = 0.5, apply_sigmoid: bool = False, return_resized: bool = False):
+    """(N,1,h,w)|(N,h,w) logits -> uint8 {0,255} masks (N,H,W) at `size`=(H,W): the bilinear resize to the original
+    image size + threshold of /root/reference/src/predict.py:620-625 (cv2.resize INTER_LINEAR, then `> THRESHOLD`)."""
+    if logits.device.type != "cuda":
+        raise RuntimeError("uwm resize_threshold runs only on a HIP device (no CPU fallback)")
+    x, xp, ld = _logit_plane(logits.detach())
+    n, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((n, H, W), dtype=torch.uint8, device=x.device)
+    rs = torch.empty((n, H, W), dtype=torch.float32, device=x.device) if return_resized else None
+    L.check(L.lib().uwm_resize_threshold(C.c_void_p(xp), ld, n, h, w, H, W, float(threshold), int(apply_sigmoid),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(rs.data_ptr() if rs is not None else 0),
+                                         C.c_void_p(L.stream_ptr(x.device))))
+    return (out, rs) if return_resized else out

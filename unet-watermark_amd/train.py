@@ -73,9 +73,11 @@ class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (coupled L2) as ONE kernel launch
     over the model's flat parameter arena (/root/reference/src/train.py:266-270 builds optim.Adam)."""
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None):
         self.model = model
         super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_grad_norm = max_grad_norm           # TRAIN.GRADIENT_CLIP (config.py:54; unused by the reference's train.py)
+        self._clip_scratch = None
         self._m = None
         self._v = None
         self._step = 0
@@ -94,10 +96,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         p = self.model.flat_parameters()
         gr = self.model.flat_grads()
-        L.check(L.lib().uwm_adam(C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._m.data_ptr()),
-                                 C.c_void_p(self._v.data_ptr()), p.numel(), float(g["lr"]), float(g["betas"][0]),
-                                 float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step,
-                                 float(grad_scale), C.c_void_p(L.stream_ptr(p.device))))
+        args = (C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._m.data_ptr()),
+                C.c_void_p(self._v.data_ptr()), p.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                float(g["eps"]), float(g["weight_decay"]), self._step, float(grad_scale))
+        if self.max_grad_norm:
+            if self._clip_scratch is None or self._clip_scratch.device != p.device:
+                self._clip_scratch = torch.zeros(2, dtype=torch.float64, device=p.device)
+            L.check(L.lib().uwm_adam_clip(*args, float(self.max_grad_norm), C.c_void_p(self._clip_scratch.data_ptr()),
+                                          C.c_void_p(L.stream_ptr(p.device))))
+        else:
+            L.check(L.lib().uwm_adam(*args, C.c_void_p(L.stream_ptr(p.device))))
         return loss
 
     def zero_grad(self, set_to_none: bool = True):
@@ -124,10 +132,10 @@ class Trainer:
 
     def __init__(self, model, w_dice: float = 1.0, w_bce: float = 0.0, smooth: float = 1e-5, eps: float = 1e-7,
                  lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0,
-                 group=None, overlap_comm: bool = True, force_ddp: bool = False):
+                 group=None, overlap_comm: bool = True, force_ddp: bool = False, max_grad_norm=None):
         self.model = model
         self.w_dice, self.w_bce, self.smooth, self.eps = float(w_dice), float(w_bce), float(smooth), float(eps)
-        self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay)
+        self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.overlap = overlap_comm
