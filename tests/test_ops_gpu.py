@@ -73,6 +73,37 @@ def test_conv_patch_tile_configs(cuda, bn, cout):
     _conv_case(cuda, 1, 32, cout, 8, 16, 3, 1, 1, cfg=100 + bn, lazy=True, seed=2)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 96), (32, 256), (128, 32), (16, 16), (16, 1), (8, 48)])
+def test_conv_winograd(cuda, cin, cout):
+    """Winograd F(2x2,3x3) kernel (conv_wino.hip), every channel-tile config (BN 64/32/16, over-hanging Cout);
+    24x40 and 9x17 pixels -> partial 8x16 workgroup tiles and partial 2x2 Winograd tiles; lazy BatchNorm+ReLU
+    input; BatchNorm statistics of the output."""
+    _conv_case(cuda, 2, cin, cout, 24, 40, 3, 1, 1, cfg=300)
+    _conv_case(cuda, 1, cin, cout, 9, 17, 3, 1, 1, cfg=300, lazy=True, seed=2)
+
+
+def test_conv_winograd_error_vs_fp64(cuda):
+    """Winograd's transforms cost a little accuracy; measured against an fp64 convolution the error must stay
+    within 4x that of the direct fp32 kernel (and far inside the 1e-3 logit budget)."""
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, h, w = 2, 128, 64, 32, 32
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (cin * 9) ** 0.5)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    xd = nhwc(x).to(cuda)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(cuda)
+    errs = {}
+    for name, cfg in (("wino", 300), ("direct", 164)):
+        y = torch.empty(n, h, w, cout, device=cuda)
+        s0 = src(xd)
+        L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), cout, kpad, 3, 3, 1, 1, n, cout, None, P(y), None, cfg, stream()))
+        torch.cuda.synchronize()
+        errs[name] = float((nchw(y.cpu()).double() - ref).abs().max())
+    assert errs["wino"] < 4 * errs["direct"] + 1e-6 and errs["wino"] < 2e-5, errs
+
+
 @pytest.mark.parametrize("cout", [16, 1, 32])
 def test_conv_patch16(cuda, cout):
     """16-channel-input kernel (whole K=144 in LDS): decoder block 4 conv2 / head / dcat-dgrad shapes;
@@ -140,6 +171,16 @@ def test_conv_upsample_concat(cuda):
 ])
 @pytest.mark.parametrize("force_igemm", [0, 1])
 def test_dgrad_and_wgrad(cuda, shape, force_igemm):
+    """force_igemm=1 also switches Winograd off, so both the direct and the Winograd dgrad are covered."""
+    L = lib()
+    L.lib().uwm_set_winograd(0 if force_igemm else 1)
+    try:
+        _dgrad_and_wgrad(cuda, shape, force_igemm)
+    finally:
+        L.lib().uwm_set_winograd(1)
+
+
+def _dgrad_and_wgrad(cuda, shape, force_igemm):
     L = lib()
     n, cin, cout, h, w, k, s, p = shape
     g = torch.Generator().manual_seed(5)

@@ -14,7 +14,7 @@ from pathlib import Path
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
     "uwm_adam_clip": (I, [P, P, P, P, L, F, F, F, F, F, L, F, F, P, P]),
     "uwm_scale": (I, [P, L, F, P]),
+    "uwm_set_winograd": (I, [I]),
     "uwm_resize_threshold": (I, [P, I, I, I, I, I, I, F, I, P, P, P]),
     "uwm_set_side_stream": (I, [P, I]),
     "uwm_prof_enable": (I, [I]),

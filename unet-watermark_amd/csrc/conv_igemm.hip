@@ -18,6 +18,7 @@
 // Reference semantics replaced: torch.nn.functional.conv2d as used by smp.Unet
 // (/root/reference/src/models/unet_model.py:64-71 -> smp; SURVEY.md §8 a3-a11,a14).
 #include "uwm_kernels.h"
+#include <cstdlib>
 
 namespace uwm {
 
@@ -251,10 +252,19 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
   return hipGetLastError();
 }
 
+static int g_winograd = -1;
+bool winograd_enabled() {
+  if (g_winograd < 0) { const char* e = getenv("UWM_WINOGRAD"); g_winograd = (e && e[0] == '0') ? 0 : 1; }
+  return g_winograd != 0;
+}
+void winograd_enable(bool on) { g_winograd = on ? 1 : 0; }
+
 // tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int cfg = force_cfg;
+  if (cfg == 300) return launch_conv_wino(a, st);
+  if (cfg < 0 && winograd_enabled() && conv_wino_applicable(a)) return launch_conv_wino(a, st);
   if (cfg == 200) return launch_conv_patch16(a, st);
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);
   if (cfg < 0 && conv_patch16_applicable(a)) return launch_conv_patch16(a, st);

@@ -1,0 +1,334 @@
+// Winograd F(2x2, 3x3) convolution (forward AND dgrad) for gfx950 on v_mfma_f32_16x16x4_f32.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input tile, g: 3x3 filter, Y: 2x2 outputs
+//
+// 16 multiplies per 4 outputs instead of 36: 2.25x fewer MFMA FLOPs than the direct form for every
+// 3x3 / stride 1 / pad 1 layer (fp32 throughout; the transforms only add and halve, so the error stays at a
+// few fp32 ulps of the direct result — tests/test_ops_gpu.py bounds it against an fp64 reference).
+//
+// Work split (one workgroup = 8x16 output pixels = 4x8 Winograd tiles of one image, BN output channels):
+//   * the 10x18 halo patch of an 8-channel chunk is staged in LDS exactly as conv_patch.hip does (lazy
+//     BatchNorm+ReLU, nearest x2 upsample, channel concat, zero padding applied while staging);
+//   * wave i (0..3) owns row i of the 4x4 Winograd domain: it builds (B^T d B)[i][0..3] for its 32 tiles
+//     straight from the patch INTO REGISTERS in MFMA B-operand layout (lane = tile, 2 channels) — the
+//     transformed input never goes through LDS — and multiplies with the pre-transformed weights
+//     U[xi][cout][c] of its four xi (LDS image is a straight copy of the global layout, conflict-free
+//     ds_read_b64);  acc[4 xi][2 tile blocks][BN/16] = 128 VGPRs for BN = 64;
+//   * epilogue: each wave reduces its row over the columns (q_b = sum_j M[i][j] A[j][b], two values), the
+//     four waves' q go through LDS once and every thread finishes Y = sum_i A^T[a][i] q_b for a 2x2 pixel
+//     block x 4 channels, then bias / residual addend / ReLU mask / BatchNorm statistics as in conv_igemm.hip.
+//
+// Pre-transformed weights (wino_weights_kernel): Ut[Ctot/8][16 xi][ceil(rows/16)][4][16][2]
+// (k-pair-major fragments: lane (co, lq) reads channels 2*lq, 2*lq+1 of its chunk).
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kTH = 8, kTW = 16, kPH = kTH + 2, kPW = kTW + 2, kPP = kPH * kPW;   // 180 patch pixels
+constexpr int kPlane = kPP * 4;                                                  // floats per 4-channel plane
+constexpr int kQPad = 4;
+
+// ---------------------------------------------------------------- filter transform U = G g G^T
+__global__ void wino_weights_kernel(const float* __restrict__ w, int wrows, int Kpad, int Ctot, int mirror,
+                                    float* __restrict__ ut, int nCb, size_t total) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % Ctot), co = (int)(i / Ctot);
+  float g[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = co < wrows ? w[(size_t)co * Kpad + (size_t)(mirror ? 8 - t : t) * Ctot + c] : 0.f;
+  float t4[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t4[0][s] = g[s];
+    t4[1][s] = 0.5f * (g[s] + g[3 + s] + g[6 + s]);
+    t4[2][s] = 0.5f * (g[s] - g[3 + s] + g[6 + s]);
+    t4[3][s] = g[6 + s];
+  }
+  const size_t base = ((size_t)(c >> 3) * 16 * nCb + (co >> 4)) * 128 + ((c & 7) >> 1) * 32 + (co & 15) * 2 + (c & 1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u0 = t4[r][0], u1 = 0.5f * (t4[r][0] + t4[r][1] + t4[r][2]), u2 = 0.5f * (t4[r][0] - t4[r][1] + t4[r][2]),
+                u3 = t4[r][2];
+    ut[base + (size_t)(r * 4 + 0) * nCb * 128] = u0;
+    ut[base + (size_t)(r * 4 + 1) * nCb * 128] = u1;
+    ut[base + (size_t)(r * 4 + 2) * nCb * 128] = u2;
+    ut[base + (size_t)(r * 4 + 3) * nCb * 128] = u3;
+  }
+}
+
+size_t wino_weights_floats(int wrows, int Ctot) { return (size_t)(Ctot / 8) * 16 * ((wrows + 15) / 16) * 128; }
+
+hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, int mirror, float* ut, hipStream_t st) {
+  if (Ctot & 7) return hipErrorInvalidValue;
+  const int nCb = (wrows + 15) / 16;
+  const size_t total = (size_t)nCb * 16 * Ctot;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, wrows, Kpad, Ctot, mirror, ut,
+                     nCb, total);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- main kernel
+template <int NI>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
+  constexpr int BN = NI * 16;
+  constexpr int UR = NI * 2;                      // 16-byte units of U per thread per chunk
+  constexpr int QLD = BN + kQPad;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Ps = smem;                         // [2 planes][180 px (pairwise swizzled)][4]
+  float* const Us = smem + 2 * kPlane;            // [16][NI][4][16][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t16 = lane & 15, lq = lane >> 4;
+
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesN = (a.Cout + BN - 1) / BN;
+  const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
+  const int tn = tile % tilesN; tile /= tilesN;
+  const int tw = tile % tilesW; tile /= tilesW;
+  const int th = tile % tilesH; const int n = tile / tilesH;
+  const int n0 = tn * BN, h0 = th * kTH, w0 = tw * kTW;
+  const int nCb = a.wu_ncb;
+
+  f4 acc[4][2][NI];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int cb = 0; cb < NI; ++cb) acc[j][tb][cb] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: patch = 360 16-byte units (2 rounds), U = NI*512 units (UR rounds), all through registers
+  f4 pv[2], psc, psh; int ppos[2]; unsigned pact = 0, phas = 0; int prelu = 0;
+  auto patch_load = [&](int cc, bool enable) {
+    pact = 0; phas = 0;
+    const int chu = tid & 1;
+    const int c = cc * 8 + chu * 4;
+    const bool first = c < a.C0;
+    const float* sp = first ? a.s0.ptr : a.s1.ptr;
+    const float* ssc = first ? a.s0.scale : a.s1.scale;
+    const float* ssh = first ? a.s0.shift : a.s1.shift;
+    const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
+    const int sup = first ? a.s0.up : a.s1.up;
+    prelu = first ? a.s0.relu : a.s1.relu;
+    const int cl = first ? c : c - a.C0;
+    if (ssc != nullptr && enable) { psc = *(const f4*)(ssc + cl); psh = *(const f4*)(ssh + cl); }
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int u = rd * 256 + tid;
+      const bool act = enable && u < kPP * 2;
+      const int pp = u >> 1;
+      const int py = pp / kPW, px = pp - py * kPW;
+      const int hl = h0 - 1 + py, wl = w0 - 1 + px;
+      const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const float* p = sp + ((size_t)((size_t)n * sH + (hl >> sup)) * sW + (wl >> sup)) * sC + cl;
+      pv[rd] = ok ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
+      pact |= (act ? 1u : 0u) << rd;
+      phas |= ((ok && ssc != nullptr) ? 1u : 0u) << rd;
+      ppos[rd] = chu * kPlane + ((pp ^ ((py >> 1) & 1)) << 2);
+    }
+  };
+  auto patch_store = [&]() {
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      if (!((pact >> rd) & 1u)) continue;
+      f4 v = pv[rd];
+      if ((phas >> rd) & 1u) {
+        v = v * psc + psh;
+        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      *(f4*)(Ps + ppos[rd]) = v;
+    }
+  };
+  f4 ur[UR];
+  auto u_load = [&](int cc, bool enable) {
+#pragma unroll
+    for (int i = 0; i < UR; ++i) {
+      const int L = i * 256 + tid;                 // f4 unit inside the [16][NI*32] chunk image
+      const int xi = L / (NI * 32), within = L - xi * (NI * 32);
+      const int cb = within >> 5;
+      const bool v = enable && (n0 / 16 + cb) < nCb;
+      const float* src = a.wu + (((size_t)cc * 16 + xi) * nCb + n0 / 16) * 128 + (size_t)within * 4;
+      ur[i] = v ? *(const f4*)src : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto u_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < UR; ++i) *(f4*)(Us + (size_t)(i * 256 + tid) * 4) = ur[i];
+  };
+
+  // ---- per-lane addresses of the B^T row pair this wave combines: r = d[ra] + sg * d[rb]
+  const int ra = (wave == 0) ? 0 : (wave == 2 ? 2 : 1);
+  const int rb = (wave == 3) ? 3 : (wave == 2 ? 1 : 2);
+  const float sg = (wave == 1) ? 1.f : -1.f;
+  int adA[2][2], adB[2][2];                         // [tb][row sel]: columns {0,2} / {1,3} (pairwise pixel swizzle)
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const int ty = tb * 2 + (t16 >> 3), tx = t16 & 7;
+      const int prow = 2 * ty + (rs ? rb : ra);
+      const int f = (prow >> 1) & 1;
+      const int base = (lq >> 1) * kPlane + ((prow * kPW + 2 * tx) << 2) + (lq & 1) * 2;
+      adA[tb][rs] = base + (f << 2);
+      adB[tb][rs] = base + ((f ^ 1) << 2);
+    }
+  const float* const ufrag = Us + wave * 4 * NI * 128 + lq * 32 + t16 * 2;
+
+  const int nchunk = a.Ctot >> 3;
+  patch_load(0, true);
+  u_load(0, true);
+  patch_store();
+  u_store();
+  __syncthreads();
+
+  for (int cc = 0; cc < nchunk; ++cc) {
+    const bool more = cc + 1 < nchunk;
+    patch_load(more ? cc + 1 : 0, more);
+    u_load(more ? cc + 1 : 0, more);
+
+    // (B^T d B)[wave][0..3] for both tile blocks, in registers
+    f2 V[2][4];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+      const f2 a0 = *(const f2*)(Ps + adA[tb][0]), a1 = *(const f2*)(Ps + adB[tb][0]);
+      const f2 a2 = *(const f2*)(Ps + adA[tb][0] + 8), a3 = *(const f2*)(Ps + adB[tb][0] + 8);
+      const f2 b0 = *(const f2*)(Ps + adA[tb][1]), b1 = *(const f2*)(Ps + adB[tb][1]);
+      const f2 b2 = *(const f2*)(Ps + adA[tb][1] + 8), b3 = *(const f2*)(Ps + adB[tb][1] + 8);
+      const f2 r0 = a0 + sg * b0, r1 = a1 + sg * b1, r2 = a2 + sg * b2, r3 = a3 + sg * b3;
+      V[tb][0] = r0 - r2; V[tb][1] = r1 + r2; V[tb][2] = r2 - r1; V[tb][3] = r1 - r3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int cb = 0; cb < NI; ++cb) {
+        const f2 wf = *(const f2*)(ufrag + (j * NI + cb) * 128);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+            acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], V[tb][j][e], acc[j][tb][cb], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                    // every wave is done with this chunk's patch and U
+    if (more) { patch_store(); u_store(); }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: q_b = sum_j M[wave][j] A[j][b]  ->  LDS  ->  Y = sum_i A^T[a][i] q_b
+  float* const Q = smem;                 // [4 waves][2][32 tiles][QLD]
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int cb = 0; cb < NI; ++cb) {
+      const f4 q0 = acc[0][tb][cb] + acc[1][tb][cb] + acc[2][tb][cb];
+      const f4 q1 = acc[1][tb][cb] - acc[2][tb][cb] - acc[3][tb][cb];
+      const int t = tb * 16 + t16;
+      *(f4*)(Q + ((wave * 2 + 0) * 32 + t) * QLD + cb * 16 + lq * 4) = q0;
+      *(f4*)(Q + ((wave * 2 + 1) * 32 + t) * QLD + cb * 16 + lq * 4) = q1;
+    }
+  __syncthreads();
+
+  constexpr int CQ = BN / 4;             // channel quads per tile
+  constexpr int ITEMS = 32 * CQ / 256;   // (tile, quad) items per thread (BN=64: 2, 32: 1)
+  static_assert(32 * CQ % 256 == 0 || 32 * CQ < 256, "item split");
+  const bool do_stats = a.ssum != nullptr;
+  f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = {0.f, 0.f, 0.f, 0.f};
+  const int cq = tid % CQ;
+  const int co = n0 + cq * 4;
+#pragma unroll
+  for (int it = 0; it < (ITEMS > 0 ? ITEMS : 1); ++it) {
+    const int item = it * 256 + tid;
+    const int t = item / CQ;
+    if (t >= 32) break;
+    f4 q[4][2];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) q[w][b] = *(const f4*)(Q + ((w * 2 + b) * 32 + t) * QLD + cq * 4);
+    const int ty = t >> 3, tx = t & 7;
+#pragma unroll
+    for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+      for (int xb = 0; xb < 2; ++xb) {
+        f4 v = ya == 0 ? q[0][xb] + q[1][xb] + q[2][xb] : q[1][xb] - q[2][xb] - q[3][xb];
+        const int ho = h0 + 2 * ty + ya, wo = w0 + 2 * tx + xb;
+        if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+          const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
+          if (a.bias) v += *(const f4*)(a.bias + co);
+          if (a.addend) v += *(const f4*)(a.addend + o);
+          if (a.mask) {
+            f4 mk = *(const f4*)(a.mask + o);
+            if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          }
+          *(f4*)(a.out + o) = v;
+          ps_ += v; pq_ += v * v;
+        }
+      }
+  }
+  if (do_stats) {
+    __syncthreads();                       // Q is dead
+    float* red = smem;                     // [256 / CQ groups][BN][2]
+    constexpr int G = (256 / CQ) < 1 ? 1 : 256 / CQ;
+    const int grp = tid / CQ;
+    if (grp < G) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[((grp * BN) + cq * 4 + e) * 2 + 0] = ps_[e];
+        red[((grp * BN) + cq * 4 + e) * 2 + 1] = pq_[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int c1 = n0 + tid;
+      if (c1 < a.Cout) {
+        double sv = 0.0, qv = 0.0;
+        for (int g = 0; g < G; ++g) { sv += (double)red[(g * BN + tid) * 2]; qv += (double)red[(g * BN + tid) * 2 + 1]; }
+        atomicAdd(a.ssum + c1, sv);
+        atomicAdd(a.ssq + c1, qv);
+      }
+    }
+  }
+}
+
+template <int NI>
+static hipError_t launch_w(const ConvArgs& a, hipStream_t st, int cls) {
+  constexpr int BN = NI * 16;
+  const int tilesN = (a.Cout + BN - 1) / BN;
+  const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
+  const size_t main_lds = (size_t)(2 * kPlane + 16 * NI * 128) * sizeof(float);
+  const size_t q_lds = (size_t)4 * 2 * 32 * (BN + kQPad) * sizeof(float);
+  const size_t lds = main_lds > q_lds ? main_lds : q_lds;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (prof_on()) prof_begin(cls, a.flops, st);
+  hipLaunchKernelGGL((conv_wino_kernel<NI>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+  if (prof_on()) prof_end(st);
+  return hipGetLastError();
+}
+
+bool conv_wino_applicable(const ConvArgs& a) {
+  return a.wu != nullptr && a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 &&
+         (a.rmul == 1 ? a.off == -1 : a.off == 1) && (a.Ctot & 7) == 0 && (a.C0 & 7) == 0 && (a.Cout & 3) == 0 &&
+         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= kTH && a.Wo >= kTW;
+}
+
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
+  if (!conv_wino_applicable(a)) return hipErrorInvalidValue;
+  if (a.Cout > 32) return launch_w<4>(a, st, 19);
+  if (a.Cout > 16) return launch_w<2>(a, st, 20);
+  return launch_w<1>(a, st, 21);
+}
+
+}  // namespace uwm

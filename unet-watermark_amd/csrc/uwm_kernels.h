@@ -43,6 +43,8 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
+  const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
+  int wu_ncb;                // 16-row blocks per xi in wu
 };
 
 struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = tap*Ctot + c)
@@ -61,7 +63,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 19 };
+enum { kProfClasses = 22 };   // 19..21 = conv_wino BN 64, 32, 16
 void prof_enable(bool on);
 bool prof_on();
 void prof_begin(int cls, double flops, hipStream_t st);
@@ -80,6 +82,13 @@ bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);
 hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn);
+// Winograd F(2x2,3x3) (conv_wino.hip): needs a.wu = launch_wino_weights(a.w ...) output; force_cfg 300
+bool conv_wino_applicable(const ConvArgs& a);
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st);
+size_t wino_weights_floats(int wrows, int Ctot);
+hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, int mirror, float* ut, hipStream_t st);
+bool winograd_enabled();
+void winograd_enable(bool on);
 
 hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st);
 hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,

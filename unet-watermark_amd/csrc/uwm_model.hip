@@ -40,6 +40,9 @@ struct ConvL {
   std::string name; int Cin, CinP, Cout, CoutP, k, stride, pad, Kpad, KpadD, stage;
   long long w_off, bias_off; int bn; bool dgrad;
   size_t wd_off;                   // workspace floats: [CinP][KpadD] dgrad repack
+  size_t wu_off, wud_off;          // workspace floats: Winograd-transformed weights (forward / dgrad); 0 = none
+  bool wino() const { return k == 3 && stride == 1 && pad == 1 && (CinP & 7) == 0; }
+  bool wino_d() const { return dgrad && k == 3 && stride == 1 && pad == 1 && (CoutP & 7) == 0; }
 };
 struct BlockL { int c1, c2, cd; };
 struct DecL { int c1, c2, C0, C1; };
@@ -86,7 +89,7 @@ static int add_conv(uwm_model* m, const std::string& name, int Cin, int Cout, in
   c.k = k; c.stride = stride; c.pad = pad; c.stage = stage; c.dgrad = dgrad;
   c.Kpad = (int)rup((long long)k * k * c.CinP, 32);
   c.KpadD = (int)rup((long long)k * k * c.CoutP, 32);
-  c.w_off = -1; c.bias_off = bias ? 0 : -1; c.wd_off = 0;
+  c.w_off = -1; c.bias_off = bias ? 0 : -1; c.wd_off = 0; c.wu_off = c.wud_off = 0;
   c.bn = bn_name.empty() ? -1 : add_bn(m, bn_name, Cout, stage);
   m->convs.push_back(c); return (int)m->convs.size() - 1;
 }
@@ -169,6 +172,10 @@ static int build_model(uwm_model* m) {
   for (auto& b : m->bns) { b.f_off = f; f += 4 * (size_t)b.C; }
   f = (size_t)rup((long long)f, 64);
   for (auto& c : m->convs) if (c.dgrad) { c.wd_off = f; f += (size_t)c.CinP * c.KpadD; f = (size_t)rup((long long)f, 64); }
+  for (auto& c : m->convs) {
+    if (c.wino()) { c.wu_off = f; f += wino_weights_floats(c.Cout, c.CinP); f = (size_t)rup((long long)f, 64); }
+    if (c.wino_d()) { c.wud_off = f; f += wino_weights_floats(c.CinP, c.CoutP); f = (size_t)rup((long long)f, 64); }
+  }
   m->fixed_floats = f;
 
   // ---- tensor infos in smp state_dict order
@@ -294,6 +301,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   if (stats && cv.bn >= 0) { const BNL& b = c.m->bns[cv.bn]; a.ssum = c.D(b.d_off); a.ssq = c.D(b.d_off) + b.C; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
+  if (cv.wu_off && a.Ctot == cv.CinP) { a.wu = c.F(cv.wu_off); a.wu_ncb = (cv.Cout + 15) / 16; }
   return launch_conv(a, c.st, cfg);
 }
 
@@ -309,6 +317,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
+  if (cv.wud_off) { a.wu = c.F(cv.wud_off); a.wu_ncb = (cv.CinP + 15) / 16; }
   return launch_conv(a, c.st);
 }
 
@@ -373,12 +382,18 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     HIPCHK(hipEventRecord(m->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     for (auto& cv : m->convs)
-      if (cv.dgrad)
+      if (cv.dgrad) {
         LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
                                cv.CoutP, m->side));
+        if (cv.wud_off && winograd_enabled())
+          LCHK(launch_wino_weights(c.F(cv.wd_off), cv.CinP, cv.KpadD, cv.CoutP, 1, c.F(cv.wud_off), m->side));
+      }
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
     m->packed_in_fwd = true;
   }
+  if (winograd_enabled())
+    for (auto& cv : m->convs)
+      if (cv.wu_off) LCHK(launch_wino_weights(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.CinP, 0, c.F(cv.wu_off), st));
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
   // eval: all BN scale/shift come from running stats and are known up front
   if (!training) for (size_t i = 0; i < m->bns.size(); ++i) LCHK(run_bn_finalize(c, (int)i, 1, 0));
@@ -463,9 +478,12 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
     } else {
       for (auto& cv : m->convs)
-        if (cv.dgrad)
+        if (cv.dgrad) {
           LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
                                  cv.CoutP, st));
+          if (cv.wud_off && winograd_enabled())
+            LCHK(launch_wino_weights(c.F(cv.wd_off), cv.CinP, cv.KpadD, cv.CoutP, 1, c.F(cv.wud_off), st));
+        }
     }
     // ---------------- head
     const ConvL& hd = m->convs[m->head];
@@ -763,6 +781,23 @@ int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* c
 }
 
 // ---- single-operator entry points
+// Winograd weights for the op-level entry points (tests): transformed into a cached scratch buffer
+static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st) {
+  static float* buf = nullptr; static size_t cap = 0;
+  const size_t need = wino_weights_floats(a.wrows, a.Ctot);
+  if (need > cap) {
+    HIPCHK(hipDeviceSynchronize());
+    if (buf) HIPCHK(hipFree(buf));
+    HIPCHK(hipMalloc((void**)&buf, need * sizeof(float))); cap = need;
+  }
+  LCHK(launch_wino_weights(a.w, a.wrows, a.Kpad, a.Ctot, mirror, buf, st));
+  a.wu = buf; a.wu_ncb = (a.wrows + 15) / 16;
+  return 0;
+}
+static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad) {
+  return kh == 3 && kw == 3 && stride == 1 && pad == 1 && (a.Ctot & 7) == 0 && (a.C0 & 7) == 0 && a.Ho >= 8 && a.Wo >= 16;
+}
+int uwm_set_winograd(int on) { winograd_enable(on != 0); return 0; }
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }
 
 int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
@@ -779,6 +814,9 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  if ((cfg == 300 || (cfg < 0 && winograd_enabled())) && op_wino_shape(a, kh, kw, stride, pad)) {
+    if (op_wino_prepare(a, 0, (hipStream_t)stream)) return 1;
+  } else if (cfg == 300) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
   LCHK(launch_conv(a, (hipStream_t)stream, cfg));
   return 0;
 }
@@ -793,6 +831,7 @@ int uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* 
   a.Hl = Ho; a.Wl = Wo; a.smul = 1; a.rmul = -1; a.off = pad; a.sdiv = stride;
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  if (winograd_enabled() && op_wino_shape(a, kh, kw, stride, pad) && op_wino_prepare(a, 1, (hipStream_t)stream)) return 1;
   LCHK(launch_conv(a, (hipStream_t)stream));
   return 0;
 }
