@@ -60,11 +60,12 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int wrows, int 
   }
 }
 
-size_t wino_weights_floats(int wrows, int Ctot) { return (size_t)(Ctot / 8) * 16 * ((wrows + 15) / 16) * 128; }
+int wino_ncb(int wrows) { return ((wrows + 63) / 64) * 4; }     // 16-row blocks per xi, padded to whole 64-row tiles (LDS-DMA cannot zero-fill)
+size_t wino_weights_floats(int wrows, int Ctot) { return (size_t)(Ctot / 8) * 16 * wino_ncb(wrows) * 128; }
 
 hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, int mirror, float* ut, hipStream_t st) {
   if (Ctot & 7) return hipErrorInvalidValue;
-  const int nCb = (wrows + 15) / 16;
+  const int nCb = wino_ncb(wrows);
   const size_t total = (size_t)nCb * 16 * Ctot;
   hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, wrows, Kpad, Ctot, mirror, ut,
                      nCb, total);
@@ -72,16 +73,23 @@ hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, in
 }
 
 // ---------------------------------------------------------------- main kernel
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+__device__ __forceinline__ void glds16(const float* g, float* l) {      // async 16 B/lane global -> LDS (wave-uniform l + lane*16)
+  __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(uintptr_t)l, 16, 0, 0);
+}
+
 template <int NI>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   constexpr int BN = NI * 16;
-  constexpr int UR = NI * 2;                      // 16-byte units of U per thread per chunk
+  constexpr int UR = NI * 2;                      // 1-KB wave-instructions of U per wave per chunk
   constexpr int QLD = BN + kQPad;
+  constexpr int kUs = 16 * NI * 128;              // floats per U buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const Ps = smem;                         // [2 planes][180 px (pairwise swizzled)][4]
-  float* const Us = smem + 2 * kPlane;            // [16][NI][4][16][2]
+  float* const Us = smem;                         // [2][16][NI][4][16][2]   (LDS-DMA destination, lane-linear)
+  float* const Ps = smem + 2 * kUs;               // [2][2 planes][180 px (pairwise swizzled)][4]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t16 = lane & 15, lq = lane >> 4;
 
   const unsigned nblk = gridDim.x, bid = blockIdx.x;
@@ -103,63 +111,64 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
       for (int cb = 0; cb < NI; ++cb) acc[j][tb][cb] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging: patch = 360 16-byte units (2 rounds), U = NI*512 units (UR rounds), all through registers
-  f4 pv[2], psc, psh; int ppos[2]; unsigned pact = 0, phas = 0; int prelu = 0;
-  auto patch_load = [&](int cc, bool enable) {
-    pact = 0; phas = 0;
+  // ---- patch staging through registers: 360 16-byte units = 2 rounds; loads are unconditional (clamped
+  // addresses, zero-selected afterwards) so the loop body has no branches
+  f4 pv[2], psc, psh; int prelu = 0; bool phas = false;
+  int ppos[2]; bool pok[2], pact[2]; int poff0[2], poff1[2];     // chunk-invariant per-thread geometry
+  {
     const int chu = tid & 1;
-    const int c = cc * 8 + chu * 4;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int u = rd * 256 + tid;
+      pact[rd] = u < kPP * 2;
+      const int pp = pact[rd] ? (u >> 1) : 0;
+      const int py = pp / kPW, px = pp - py * kPW;
+      const int hl = h0 - 1 + py, wl = w0 - 1 + px;
+      pok[rd] = pact[rd] && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+      poff0[rd] = (int)(((size_t)n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C + chu * 4;
+      poff1[rd] = (int)(((size_t)n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C + chu * 4;
+      ppos[rd] = chu * kPlane + ((pp ^ ((py >> 1) & 1)) << 2);
+    }
+  }
+  auto patch_load = [&](int cc) {
+    const int c = cc * 8;                           // chunk base channel (chunks never straddle the two sources)
     const bool first = c < a.C0;
     const float* sp = first ? a.s0.ptr : a.s1.ptr;
     const float* ssc = first ? a.s0.scale : a.s1.scale;
     const float* ssh = first ? a.s0.shift : a.s1.shift;
-    const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
-    const int sup = first ? a.s0.up : a.s1.up;
     prelu = first ? a.s0.relu : a.s1.relu;
-    const int cl = first ? c : c - a.C0;
-    if (ssc != nullptr && enable) { psc = *(const f4*)(ssc + cl); psh = *(const f4*)(ssh + cl); }
+    const int cl = (first ? c : c - a.C0);
+    phas = ssc != nullptr;
+    if (phas) { psc = *(const f4*)(ssc + cl + (tid & 1) * 4); psh = *(const f4*)(ssh + cl + (tid & 1) * 4); }
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int u = rd * 256 + tid;
-      const bool act = enable && u < kPP * 2;
-      const int pp = u >> 1;
-      const int py = pp / kPW, px = pp - py * kPW;
-      const int hl = h0 - 1 + py, wl = w0 - 1 + px;
-      const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
-      const float* p = sp + ((size_t)((size_t)n * sH + (hl >> sup)) * sW + (wl >> sup)) * sC + cl;
-      pv[rd] = ok ? *(const f4*)p : (f4){0.f, 0.f, 0.f, 0.f};
-      pact |= (act ? 1u : 0u) << rd;
-      phas |= ((ok && ssc != nullptr) ? 1u : 0u) << rd;
-      ppos[rd] = chu * kPlane + ((pp ^ ((py >> 1) & 1)) << 2);
-    }
+    for (int rd = 0; rd < 2; ++rd) pv[rd] = *(const f4*)(sp + (first ? poff0[rd] : poff1[rd]) + cl);
   };
-  auto patch_store = [&]() {
+  auto patch_store = [&](int buf) {
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
-      if (!((pact >> rd) & 1u)) continue;
       f4 v = pv[rd];
-      if ((phas >> rd) & 1u) {
+      if (phas) {
         v = v * psc + psh;
         if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
-      *(f4*)(Ps + ppos[rd]) = v;
+      if (!pok[rd]) v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (pact[rd]) *(f4*)(Ps + buf * 2 * kPlane + ppos[rd]) = v;
     }
   };
-  f4 ur[UR];
-  auto u_load = [&](int cc, bool enable) {
+  // ---- U chunk: UR LDS-DMA instructions per wave, 1 KB each, straight copy of the global image
+  const float* const ug = a.wu + (size_t)(n0 / 16) * 128;
+  int uoff[UR];                                     // per-lane source offset of each wave-instruction (chunk 0)
 #pragma unroll
-    for (int i = 0; i < UR; ++i) {
-      const int L = i * 256 + tid;                 // f4 unit inside the [16][NI*32] chunk image
-      const int xi = L / (NI * 32), within = L - xi * (NI * 32);
-      const int cb = within >> 5;
-      const bool v = enable && (n0 / 16 + cb) < nCb;
-      const float* src = a.wu + (((size_t)cc * 16 + xi) * nCb + n0 / 16) * 128 + (size_t)within * 4;
-      ur[i] = v ? *(const f4*)src : (f4){0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  auto u_store = [&]() {
+  for (int i = 0; i < UR; ++i) {
+    const int L = (i * 4 + wave) * 64 + lane;       // f4 unit in the [16][NI*32] chunk image
+    const int xi = L / (NI * 32), within = L - xi * (NI * 32);
+    uoff[i] = xi * nCb * 128 + within * 4;
+  }
+  auto u_dma = [&](int cc, int buf) {
+    const float* const uc = ug + (size_t)cc * 16 * nCb * 128;
 #pragma unroll
-    for (int i = 0; i < UR; ++i) *(f4*)(Us + (size_t)(i * 256 + tid) * 4) = ur[i];
+    for (int i = 0; i < UR; ++i) glds16(uc + uoff[i], Us + buf * kUs + (i * 4 + wave) * 256);
   };
 
   // ---- per-lane addresses of the B^T row pair this wave combines: r = d[ra] + sg * d[rb]
@@ -178,50 +187,58 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
       adA[tb][rs] = base + (f << 2);
       adB[tb][rs] = base + ((f ^ 1) << 2);
     }
-  const float* const ufrag = Us + wave * 4 * NI * 128 + lq * 32 + t16 * 2;
+  const int ufrag = wave * 4 * NI * 128 + lq * 32 + t16 * 2;
 
   const int nchunk = a.Ctot >> 3;
-  patch_load(0, true);
-  u_load(0, true);
-  patch_store();
-  u_store();
+  u_dma(0, 0);
+  patch_load(0);
+  patch_store(0);
   __syncthreads();
 
   for (int cc = 0; cc < nchunk; ++cc) {
-    const bool more = cc + 1 < nchunk;
-    patch_load(more ? cc + 1 : 0, more);
-    u_load(more ? cc + 1 : 0, more);
+    const int cur = cc & 1, nxt = cur ^ 1;
+    const int cn = cc + 1 < nchunk ? cc + 1 : cc;   // last chunk: harmless re-fetch into the dead buffer
+    u_dma(cn, nxt);
+    patch_load(cn);
+    __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ABOVE the MFMA block (hipcc otherwise sinks it to the end)
 
     // (B^T d B)[wave][0..3] for both tile blocks, in registers
+    const float* const pc = Ps + cur * 2 * kPlane;
     f2 V[2][4];
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
-      const f2 a0 = *(const f2*)(Ps + adA[tb][0]), a1 = *(const f2*)(Ps + adB[tb][0]);
-      const f2 a2 = *(const f2*)(Ps + adA[tb][0] + 8), a3 = *(const f2*)(Ps + adB[tb][0] + 8);
-      const f2 b0 = *(const f2*)(Ps + adA[tb][1]), b1 = *(const f2*)(Ps + adB[tb][1]);
-      const f2 b2 = *(const f2*)(Ps + adA[tb][1] + 8), b3 = *(const f2*)(Ps + adB[tb][1] + 8);
+      const f2 a0 = *(const f2*)(pc + adA[tb][0]), a1 = *(const f2*)(pc + adB[tb][0]);
+      const f2 a2 = *(const f2*)(pc + adA[tb][0] + 8), a3 = *(const f2*)(pc + adB[tb][0] + 8);
+      const f2 b0 = *(const f2*)(pc + adA[tb][1]), b1 = *(const f2*)(pc + adB[tb][1]);
+      const f2 b2 = *(const f2*)(pc + adA[tb][1] + 8), b3 = *(const f2*)(pc + adB[tb][1] + 8);
       const f2 r0 = a0 + sg * b0, r1 = a1 + sg * b1, r2 = a2 + sg * b2, r3 = a3 + sg * b3;
       V[tb][0] = r0 - r2; V[tb][1] = r1 + r2; V[tb][2] = r2 - r1; V[tb][3] = r1 - r3;
     }
+    const float* const uc = Us + cur * kUs + ufrag;
+    f2 wf[2][NI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int cb = 0; cb < NI; ++cb) wf[0][cb] = *(const f2*)(uc + cb * 128);
 #pragma unroll
-      for (int cb = 0; cb < NI; ++cb) {
-        const f2 wf = *(const f2*)(ufrag + (j * NI + cb) * 128);
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) {
+#pragma unroll
+        for (int cb = 0; cb < NI; ++cb) wf[(j + 1) & 1][cb] = *(const f2*)(uc + ((j + 1) * NI + cb) * 128);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NI; ++cb)
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int tb = 0; tb < 2; ++tb)
-            acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], V[tb][j][e], acc[j][tb][cb], 0, 0, 0);
-      }
+            acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j & 1][cb][e], V[tb][j][e], acc[j][tb][cb], 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                    // every wave is done with this chunk's patch and U
-    if (more) { patch_store(); u_store(); }
-    __syncthreads();
+    patch_store(nxt);
+    __syncthreads();                    // next chunk's U (LDS-DMA) and patch have landed; everyone is done with `cur`
   }
 
   // ---------------- epilogue: q_b = sum_j M[wave][j] A[j][b]  ->  LDS  ->  Y = sum_i A^T[a][i] q_b
-  float* const Q = smem;                 // [4 waves][2][32 tiles][QLD]
+  float* const Q = smem;                 // [4 waves][2][32 tiles][QLD]  (main-loop LDS is dead: last barrier passed)
 #pragma unroll
   for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -303,7 +320,7 @@ static hipError_t launch_w(const ConvArgs& a, hipStream_t st, int cls) {
   constexpr int BN = NI * 16;
   const int tilesN = (a.Cout + BN - 1) / BN;
   const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
-  const size_t main_lds = (size_t)(2 * kPlane + 16 * NI * 128) * sizeof(float);
+  const size_t main_lds = (size_t)2 * (2 * kPlane + 16 * NI * 128) * sizeof(float);
   const size_t q_lds = (size_t)4 * 2 * 32 * (BN + kQPad) * sizeof(float);
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
   static bool attr_set = false;
@@ -321,7 +338,8 @@ static hipError_t launch_w(const ConvArgs& a, hipStream_t st, int cls) {
 bool conv_wino_applicable(const ConvArgs& a) {
   return a.wu != nullptr && a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 &&
          (a.rmul == 1 ? a.off == -1 : a.off == 1) && (a.Ctot & 7) == 0 && (a.C0 & 7) == 0 && (a.Cout & 3) == 0 &&
-         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= kTH && a.Wo >= kTW;
+         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= kTH && a.Wo >= kTW &&
+         (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < 0x7fffffffull && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < 0x7fffffffull;   // 32-bit patch offsets
 }
 
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {

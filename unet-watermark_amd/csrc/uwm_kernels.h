@@ -86,6 +86,7 @@ hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn);
 bool conv_wino_applicable(const ConvArgs& a);
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st);
 size_t wino_weights_floats(int wrows, int Ctot);
+int wino_ncb(int wrows);
 hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, int mirror, float* ut, hipStream_t st);
 bool winograd_enabled();
 void winograd_enable(bool on);

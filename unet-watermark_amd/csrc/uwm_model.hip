@@ -301,7 +301,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   if (stats && cv.bn >= 0) { const BNL& b = c.m->bns[cv.bn]; a.ssum = c.D(b.d_off); a.ssq = c.D(b.d_off) + b.C; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
-  if (cv.wu_off && a.Ctot == cv.CinP) { a.wu = c.F(cv.wu_off); a.wu_ncb = (cv.Cout + 15) / 16; }
+  if (cv.wu_off && a.Ctot == cv.CinP) { a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout); }
   return launch_conv(a, c.st, cfg);
 }
 
@@ -317,7 +317,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
-  if (cv.wud_off) { a.wu = c.F(cv.wud_off); a.wu_ncb = (cv.CinP + 15) / 16; }
+  if (cv.wud_off) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
   return launch_conv(a, c.st);
 }
 
@@ -791,7 +791,7 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st) {
     HIPCHK(hipMalloc((void**)&buf, need * sizeof(float))); cap = need;
   }
   LCHK(launch_wino_weights(a.w, a.wrows, a.Kpad, a.Ctot, mirror, buf, st));
-  a.wu = buf; a.wu_ncb = (a.wrows + 15) / 16;
+  a.wu = buf; a.wu_ncb = wino_ncb(a.wrows);
   return 0;
 }
 static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad) {
