@@ -169,11 +169,12 @@ def test_conv_upsample_concat(cuda):
     (1, 32, 16, 32, 48, 3, 1, 1),     # dgrad runs conv_patch16<32> (dy has 16 channels)
     (2, 16, 16, 16, 32, 3, 1, 1),     # dgrad runs conv_patch16<16>
 ])
-@pytest.mark.parametrize("force_igemm", [0, 1])
+@pytest.mark.parametrize("force_igemm", [0, 1, 2])
 def test_dgrad_and_wgrad(cuda, shape, force_igemm):
-    """force_igemm=1 also switches Winograd off, so both the direct and the Winograd dgrad are covered."""
+    """force_igemm: 0 = auto (Winograd dgrad / Winograd-domain wgrad where applicable), 1 = flattened implicit GEMM
+    wgrad with Winograd off (direct dgrad kernels), 2 = patch wgrad with Winograd on."""
     L = lib()
-    L.lib().uwm_set_winograd(0 if force_igemm else 1)
+    L.lib().uwm_set_winograd(0 if force_igemm == 1 else 1)
     try:
         _dgrad_and_wgrad(cuda, shape, force_igemm)
     finally:

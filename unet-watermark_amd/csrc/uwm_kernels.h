@@ -63,7 +63,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 22 };   // 19..21 = conv_wino BN 64, 32, 16
+enum { kProfClasses = 25 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16
 void prof_enable(bool on);
 bool prof_on();
 void prof_begin(int cls, double flops, hipStream_t st);
@@ -78,6 +78,8 @@ hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st);
 // force_cfg for launch_conv: -1 auto, 0..5 conv_igemm tile config, 100+BN (116,132,164,228) conv_patch, 200 conv_patch16
 bool wgrad_patch_applicable(const WgradArgs& a);
 hipError_t launch_wgrad_patch(const WgradArgs& a, hipStream_t st);
+bool wgrad_wino_applicable(const WgradArgs& a);            // Winograd-domain wgrad (wgrad_wino.hip)
+hipError_t launch_wgrad_wino(const WgradArgs& a, hipStream_t st);
 bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);

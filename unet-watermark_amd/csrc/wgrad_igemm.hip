@@ -211,7 +211,9 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
 
 // tile (output channels x k-columns) chosen from the layer's Cout: 16x256, 32x256, 64x128, 128x128
 hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
-  if ((a0.force_igemm & 0xff) == 0 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);
+  // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd
+  if ((a0.force_igemm & 0xff) == 0 && winograd_enabled() && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
+  if ((a0.force_igemm & 0xff) != 1 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);
   WgradArgs a = a0;
   if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int TA, TB;
