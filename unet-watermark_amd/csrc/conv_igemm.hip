@@ -19,6 +19,7 @@
 // (/root/reference/src/models/unet_model.py:64-71 -> smp; SURVEY.md §8 a3-a11,a14).
 #include "uwm_kernels.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace uwm {
 
@@ -263,7 +264,12 @@ void winograd_enable(bool on) { g_winograd = on ? 1 : 0; }
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int cfg = force_cfg;
-  if (cfg == 300) return launch_conv_wino(a, st);
+  static const bool trace = getenv("UWM_TRACE_CONV") != nullptr;
+  if (trace)
+    fprintf(stderr, "conv %s N=%d Ctot=%d(C0=%d up=%d) Cout=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d smul=%d sdiv=%d wino=%d gflop=%.2f\n",
+            a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
+            (int)(cfg < 0 && winograd_enabled() && conv_wino_applicable(a)), a.flops * 1e-9);
+  if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
   if (cfg < 0 && winograd_enabled() && conv_wino_applicable(a)) return launch_conv_wino(a, st);
   if (cfg == 200) return launch_conv_patch16(a, st);
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);

@@ -60,6 +60,47 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int wrows, int 
   }
 }
 
+// all layers of a model in one launch: blockIdx.y = job.  mode 0: U from [rows][Kpad] weights (k = tap*chans + c);
+// mode 2: the dgrad filter bank straight from the FORWARD weights: rows = input channels, chans = output
+// channels, g'[r][s] = w[c][(2-r)*3 + (2-s)][row]  (transposed + mirrored), no intermediate repack
+__global__ void wino_weights_multi_kernel(const WinoJobs jobs) {
+  const WinoJob jb = jobs.j[blockIdx.y];
+  const int nCb = ((jb.rows + 63) / 64) * 4;
+  const size_t total = (size_t)nCb * 16 * jb.chans;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % jb.chans), row = (int)(i / jb.chans);
+    float g[9];
+    if (jb.mode == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = row < jb.rows ? jb.w[(size_t)row * jb.Kpad + (size_t)t * jb.chans + c] : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = (row < jb.rows && c < jb.src_rows) ? jb.w[(size_t)c * jb.Kpad + (size_t)(8 - t) * jb.rows + row] : 0.f;
+    }
+    float t4[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      t4[0][s] = g[s];
+      t4[1][s] = 0.5f * (g[s] + g[3 + s] + g[6 + s]);
+      t4[2][s] = 0.5f * (g[s] - g[3 + s] + g[6 + s]);
+      t4[3][s] = g[6 + s];
+    }
+    const size_t base = ((size_t)(c >> 3) * 16 * nCb + (row >> 4)) * 128 + ((c & 7) >> 1) * 32 + (row & 15) * 2 + (c & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      jb.ut[base + (size_t)(r * 4 + 0) * nCb * 128] = t4[r][0];
+      jb.ut[base + (size_t)(r * 4 + 1) * nCb * 128] = 0.5f * (t4[r][0] + t4[r][1] + t4[r][2]);
+      jb.ut[base + (size_t)(r * 4 + 2) * nCb * 128] = 0.5f * (t4[r][0] - t4[r][1] + t4[r][2]);
+      jb.ut[base + (size_t)(r * 4 + 3) * nCb * 128] = t4[r][2];
+    }
+  }
+}
+hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st) {
+  if (jobs.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(wino_weights_multi_kernel, dim3(64, (unsigned)jobs.n), dim3(256), 0, st, jobs);
+  return hipGetLastError();
+}
+
 int wino_ncb(int wrows) { return ((wrows + 63) / 64) * 4; }     // 16-row blocks per xi, padded to whole 64-row tiles (LDS-DMA cannot zero-fill)
 size_t wino_weights_floats(int wrows, int Ctot) { return (size_t)(Ctot / 8) * 16 * wino_ncb(wrows) * 128; }
 
@@ -342,11 +383,21 @@ bool conv_wino_applicable(const ConvArgs& a) {
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < 0x7fffffffull && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < 0x7fffffffull;   // 32-bit patch offsets
 }
 
-hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st) {
+// bn: 0 auto | 64 | 32 | 16 output channels per workgroup
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn) {
   if (!conv_wino_applicable(a)) return hipErrorInvalidValue;
-  if (a.Cout > 32) return launch_w<4>(a, st, 19);
-  if (a.Cout > 16) return launch_w<2>(a, st, 20);
-  return launch_w<1>(a, st, 21);
+  if (bn <= 0) {
+    bn = a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16);
+    // deep, spatially small layers: 64-channel tiles leave half the workgroup slots empty -> 32-channel tiles
+    const long sp = (long)a.N * ((a.Ho + kTH - 1) / kTH) * ((a.Wo + kTW - 1) / kTW);
+    if (bn == 64 && sp * ((a.Cout + 63) / 64) < 512) bn = 32;
+  }
+  switch (bn) {
+    case 64: return launch_w<4>(a, st, 19);
+    case 32: return launch_w<2>(a, st, 20);
+    case 16: return launch_w<1>(a, st, 21);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace uwm

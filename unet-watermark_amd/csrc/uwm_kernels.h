@@ -84,12 +84,15 @@ bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);
 hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn);
-// Winograd F(2x2,3x3) (conv_wino.hip): needs a.wu = launch_wino_weights(a.w ...) output; force_cfg 300
+// Winograd F(2x2,3x3) (conv_wino.hip): needs a.wu = launch_wino_weights(a.w ...) output; force_cfg 300 (auto tile) / 300+BN
 bool conv_wino_applicable(const ConvArgs& a);
-hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st);
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn = 0);
 size_t wino_weights_floats(int wrows, int Ctot);
 int wino_ncb(int wrows);
 hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, int mirror, float* ut, hipStream_t st);
+struct WinoJob { const float* w; float* ut; int rows, chans, Kpad, mode, src_rows, pad_; };
+struct WinoJobs { WinoJob j[40]; int n; };
+hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st);   // every layer's transform in one launch
 bool winograd_enabled();
 void winograd_enable(bool on);
 

@@ -52,6 +52,8 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   size_t bytes = 0;
   size_t x4 = 0, pool = 0, pool_idx = 0, g_pool = 0, tmp = 0, loss_scr = 0;
   std::vector<size_t> y, g;         // per conv: raw output / its gradient buffer (float offsets)
+  std::vector<int> oh, ow;          // per conv: output height / width
+  bool wino_ok(size_t ci) const { return winograd_enabled() && oh[ci] >= 8 && ow[ci] >= 16; }   // conv_wino tile fits
   std::vector<size_t> xn, gx;       // per encoder block: residual output / its gradient
   std::vector<size_t> dcat, gskip;  // per decoder block
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
@@ -209,12 +211,12 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   size_t off = m->fixed_floats;
   auto alloc = [&](size_t floats) { size_t o = off; off += (size_t)rup((long long)floats, 64); return o; };
   const size_t nc = m->convs.size();
-  p.y.assign(nc, 0); p.g.assign(nc, 0);
+  p.y.assign(nc, 0); p.g.assign(nc, 0); p.oh.assign(nc, 0); p.ow.assign(nc, 0);
   p.stat_d = 0; p.stat_d_count = 0; for (auto& b : m->bns) p.stat_d_count += 4 * (size_t)b.C;
   p.loss_scr = alloc(64);
   p.x4 = alloc((size_t)N * H * W * m->CinP);
   int h = H / 2, w = W / 2;
-  p.y[m->stem] = alloc((size_t)N * h * w * 64);
+  p.y[m->stem] = alloc((size_t)N * h * w * 64); p.oh[m->stem] = h; p.ow[m->stem] = w;
   h /= 2; w /= 2;
   p.pool = alloc((size_t)N * h * w * 64);
   p.pool_idx = alloc((size_t)N * h * w * 64 / 4 + 64);
@@ -228,7 +230,8 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       h /= c1.stride; w /= c1.stride;
       const size_t sz = (size_t)N * h * w * c1.Cout;
       p.y[bl.c1] = alloc(sz); p.y[bl.c2] = alloc(sz);
-      if (bl.cd >= 0) p.y[bl.cd] = alloc(sz);
+      p.oh[bl.c1] = p.oh[bl.c2] = h; p.ow[bl.c1] = p.ow[bl.c2] = w;
+      if (bl.cd >= 0) { p.y[bl.cd] = alloc(sz); p.oh[bl.cd] = h; p.ow[bl.cd] = w; }
       p.xn[bi++] = alloc(sz);
       if (sz > max_in) max_in = sz;
     }
@@ -238,7 +241,9 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
     h *= 2; w *= 2;
     const size_t sz = (size_t)N * h * w * m->convs[m->dec[i].c1].Cout;
     p.y[m->dec[i].c1] = alloc(sz); p.y[m->dec[i].c2] = alloc(sz);
+    p.oh[m->dec[i].c1] = p.oh[m->dec[i].c2] = h; p.ow[m->dec[i].c1] = p.ow[m->dec[i].c2] = w;
   }
+  p.oh[m->head] = H; p.ow[m->head] = W;
   if (training) {
     // gradient buffers (same shapes as their activations)
     h = H / 2; w = W / 2;
@@ -301,7 +306,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   if (stats && cv.bn >= 0) { const BNL& b = c.m->bns[cv.bn]; a.ssum = c.D(b.d_off); a.ssq = c.D(b.d_off) + b.C; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
-  if (cv.wu_off && a.Ctot == cv.CinP) { a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout); }
+  if (cv.wu_off && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout); }
   return launch_conv(a, c.st, cfg);
 }
 
@@ -317,7 +322,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
-  if (cv.wud_off) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
+  if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
   return launch_conv(a, c.st);
 }
 
@@ -368,6 +373,24 @@ static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, si
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("launch failed: %s at %s:%d (%s)",  \
        hipGetErrorString(e_), __FILE__, __LINE__, #expr); } while (0)
 
+// Winograd filter transforms of every eligible layer (forward banks, or dgrad banks straight from the forward
+// weights), at most 40 layers per launch
+static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
+  if (!winograd_enabled()) return hipSuccess;
+  WinoJobs jobs; jobs.n = 0;
+  const uwm_model* m = c.m;
+  for (size_t ci = 0; ci < m->convs.size(); ++ci) {
+    const ConvL& cv = m->convs[ci];
+    if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off)) continue;
+    WinoJob& j = jobs.j[jobs.n++];
+    j.w = m->params + cv.w_off; j.Kpad = cv.Kpad; j.pad_ = 0;
+    if (dgrad) { j.ut = c.F(cv.wud_off); j.rows = cv.CinP; j.chans = cv.CoutP; j.mode = 2; j.src_rows = cv.Cout; }
+    else { j.ut = c.F(cv.wu_off); j.rows = cv.Cout; j.chans = cv.CinP; j.mode = 0; j.src_rows = cv.Cout; }
+    if (jobs.n == 40) { hipError_t e = launch_wino_weights_multi(jobs, st); if (e != hipSuccess) return e; jobs.n = 0; }
+  }
+  return launch_wino_weights_multi(jobs, st);
+}
+
 // ------------------------------------------------------------------------------ forward
 static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, int N, int H, int W, int training,
                       hipStream_t st) {
@@ -381,19 +404,17 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     // so they cost nothing; uwm_backward waits for ev_pack
     HIPCHK(hipEventRecord(m->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    for (auto& cv : m->convs)
-      if (cv.dgrad) {
+    for (size_t ci = 0; ci < m->convs.size(); ++ci) {
+      const ConvL& cv = m->convs[ci];
+      if (cv.dgrad && !(cv.wud_off && p.wino_ok(ci)))      // Winograd dgrads take their filters from wino_jobs below
         LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
                                cv.CoutP, m->side));
-        if (cv.wud_off && winograd_enabled())
-          LCHK(launch_wino_weights(c.F(cv.wd_off), cv.CinP, cv.KpadD, cv.CoutP, 1, c.F(cv.wud_off), m->side));
-      }
+    }
+    LCHK(wino_jobs(c, true, m->side));
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
     m->packed_in_fwd = true;
   }
-  if (winograd_enabled())
-    for (auto& cv : m->convs)
-      if (cv.wu_off) LCHK(launch_wino_weights(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.CinP, 0, c.F(cv.wu_off), st));
+  LCHK(wino_jobs(c, false, st));
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
   // eval: all BN scale/shift come from running stats and are known up front
   if (!training) for (size_t i = 0; i < m->bns.size(); ++i) LCHK(run_bn_finalize(c, (int)i, 1, 0));
@@ -477,13 +498,13 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     if (m->packed_in_fwd) {
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
     } else {
-      for (auto& cv : m->convs)
-        if (cv.dgrad) {
+      for (size_t ci = 0; ci < m->convs.size(); ++ci) {
+        const ConvL& cv = m->convs[ci];
+        if (cv.dgrad && !(cv.wud_off && p.wino_ok(ci)))
           LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
                                  cv.CoutP, st));
-          if (cv.wud_off && winograd_enabled())
-            LCHK(launch_wino_weights(c.F(cv.wd_off), cv.CinP, cv.KpadD, cv.CoutP, 1, c.F(cv.wud_off), st));
-        }
+      }
+      LCHK(wino_jobs(c, true, st));
     }
     // ---------------- head
     const ConvL& hd = m->convs[m->head];
@@ -814,9 +835,9 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
-  if ((cfg == 300 || (cfg < 0 && winograd_enabled())) && op_wino_shape(a, kh, kw, stride, pad)) {
+  if ((cfg >= 300 || (cfg < 0 && winograd_enabled())) && op_wino_shape(a, kh, kw, stride, pad)) {
     if (op_wino_prepare(a, 0, (hipStream_t)stream)) return 1;
-  } else if (cfg == 300) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
+  } else if (cfg >= 300) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
   LCHK(launch_conv(a, (hipStream_t)stream, cfg));
   return 0;
 }

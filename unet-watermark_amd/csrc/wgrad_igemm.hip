@@ -12,6 +12,8 @@
 //
 // Replaces the weight-gradient half of autograd's conv2d backward.
 #include "uwm_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace uwm {
 
@@ -211,6 +213,11 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
 
 // tile (output channels x k-columns) chosen from the layer's Cout: 16x256, 32x256, 64x128, 128x128
 hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
+  static const bool trace = getenv("UWM_TRACE_CONV") != nullptr;
+  if (trace)
+    fprintf(stderr, "wgrad N=%d Ctot=%d(C0=%d) Cout=%d wrows=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d stride=%d wino=%d patch=%d gflop=%.2f\n", a0.N, a0.Ctot,
+            a0.C0, a0.Cout, a0.wrows, a0.Ho, a0.Wo, a0.Hl, a0.Wl, a0.ntaps, a0.stride, (int)(winograd_enabled() && wgrad_wino_applicable(a0)),
+            (int)wgrad_patch_applicable(a0), a0.flops * 1e-9);
   // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd
   if ((a0.force_igemm & 0xff) == 0 && winograd_enabled() && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
   if ((a0.force_igemm & 0xff) != 1 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);
