@@ -122,7 +122,8 @@ int  uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, fl
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
 /* 3x3/stride-1 convolutions (forward and dgrad) run as Winograd F(2x2,3x3) on the fp32 MFMA path by default
  * (2.25x fewer multiplies, results within a few fp32 ulps of the direct form); 0 selects the direct kernels
- * everywhere.  Process-wide; also UWM_WINOGRAD=0 in the environment. */
+ * everywhere; 2 (tests) prefers the 512-thread Winograd variant wherever its shape rules allow, whatever the
+ * launch size.  Process-wide; also UWM_WINOGRAD=0 in the environment. */
 int  uwm_set_winograd(int on);
 /* predict.py:620-625 on the device: bilinear resize (cv2.INTER_LINEAR convention) of each image's logit plane
  * [N][h][w] (element stride ld) to [N][H][W], then (v > threshold) ? 255 : 0.  mask and/or resized may be NULL. */

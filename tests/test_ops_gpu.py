@@ -82,6 +82,14 @@ def test_conv_winograd(cuda, cin, cout):
     _conv_case(cuda, 1, cin, cout, 9, 17, 3, 1, 1, cfg=300, lazy=True, seed=2)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 160), (8, 64), (128, 96)])
+def test_conv_winograd_8wave(cuda, cin, cout):
+    """512-thread / 16x16-pixel Winograd variant (conv_wino8.hip): partial tiles in both directions, over-hanging
+    Cout, single-chunk K (cin 8), lazy input, BatchNorm statistics."""
+    _conv_case(cuda, 2, cin, cout, 24, 40, 3, 1, 1, cfg=308)
+    _conv_case(cuda, 1, cin, cout, 17, 33, 3, 1, 1, cfg=308, lazy=True, seed=2)
+
+
 def test_conv_winograd_error_vs_fp64(cuda):
     """Winograd's transforms cost a little accuracy; measured against an fp64 convolution the error must stay
     within 4x that of the direct fp32 kernel (and far inside the 1e-3 logit budget)."""
@@ -169,14 +177,15 @@ def test_conv_upsample_concat(cuda):
     (1, 32, 16, 32, 48, 3, 1, 1),     # dgrad runs conv_patch16<32> (dy has 16 channels)
     (2, 16, 16, 16, 32, 3, 1, 1),     # dgrad runs conv_patch16<16>
 ])
-@pytest.mark.parametrize("force_igemm", [0, 1, 2])
+@pytest.mark.parametrize("force_igemm", [0, 1, 2, 3])
 def test_dgrad_and_wgrad(cuda, shape, force_igemm):
     """force_igemm: 0 = auto (Winograd dgrad / Winograd-domain wgrad where applicable), 1 = flattened implicit GEMM
-    wgrad with Winograd off (direct dgrad kernels), 2 = patch wgrad with Winograd on."""
+    wgrad with Winograd off (direct dgrad kernels), 2 = patch wgrad with Winograd on, 3 = auto with the 8-wave
+    Winograd variant preferred (dgrad through conv_wino8 where the shape allows)."""
     L = lib()
-    L.lib().uwm_set_winograd(0 if force_igemm == 1 else 1)
+    L.lib().uwm_set_winograd({0: 1, 1: 0, 2: 1, 3: 2}[force_igemm])
     try:
-        _dgrad_and_wgrad(cuda, shape, force_igemm)
+        _dgrad_and_wgrad(cuda, shape, 0 if force_igemm == 3 else force_igemm)
     finally:
         L.lib().uwm_set_winograd(1)
 

@@ -14,7 +14,7 @@ from pathlib import Path
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
 
 
@@ -119,6 +119,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    if os.environ.get("UWM_LIB"):          # experiments: load an alternative build of the same library
+        LIB_PATH = Path(os.environ["UWM_LIB"])
     if not LIB_PATH.exists():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "

@@ -259,6 +259,8 @@ bool winograd_enabled() {
   return g_winograd != 0;
 }
 void winograd_enable(bool on) { g_winograd = on ? 1 : 0; }
+void winograd_set_mode(int mode) { g_winograd = mode; }
+int winograd_mode() { (void)winograd_enabled(); return g_winograd; }
 
 // tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {

@@ -26,6 +26,9 @@ namespace uwm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef UWM_WINO_ABL
+#define UWM_WINO_ABL 0
+#endif
 
 constexpr int kTH = 8, kTW = 16, kPH = kTH + 2, kPW = kTW + 2, kPP = kPH * kPW;   // 180 patch pixels
 constexpr int kPlane = kPP * 4;                                                  // floats per 4-channel plane
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   const int th = tile % tilesH; const int n = tile / tilesH;
   const int n0 = tn * BN, h0 = th * kTH, w0 = tw * kTW;
   const int nCb = a.wu_ncb;
+  constexpr int dbg = UWM_WINO_ABL;       // compile-time timing ablations (scripts/ablate_wino.sh); 0 in the product build
 
   f4 acc[4][2][NI];
 #pragma unroll
@@ -239,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   for (int cc = 0; cc < nchunk; ++cc) {
     const int cur = cc & 1, nxt = cur ^ 1;
     const int cn = cc + 1 < nchunk ? cc + 1 : cc;   // last chunk: harmless re-fetch into the dead buffer
-    u_dma(cn, nxt);
-    patch_load(cn);
+    if (!(dbg & 2)) u_dma(cn, nxt);
+    if (!(dbg & 4)) patch_load(cn);
     __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ABOVE the MFMA block (hipcc otherwise sinks it to the end)
 
     // (B^T d B)[wave][0..3] for both tile blocks, in registers
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     f2 V[2][4];
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
+      if (dbg & 8) { V[tb][0] = V[tb][1] = V[tb][2] = V[tb][3] = (f2){1.f, 2.f}; continue; }
       const f2 a0 = *(const f2*)(pc + adA[tb][0]), a1 = *(const f2*)(pc + adB[tb][0]);
       const f2 a2 = *(const f2*)(pc + adA[tb][0] + 8), a3 = *(const f2*)(pc + adB[tb][0] + 8);
       const f2 b0 = *(const f2*)(pc + adA[tb][1]), b1 = *(const f2*)(pc + adB[tb][1]);
@@ -258,12 +263,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     const float* const uc = Us + cur * kUs + ufrag;
     f2 wf[2][NI];
 #pragma unroll
-    for (int cb = 0; cb < NI; ++cb) wf[0][cb] = *(const f2*)(uc + cb * 128);
+    for (int cb = 0; cb < NI; ++cb) wf[0][cb] = (dbg & 16) ? (f2){1.f, 1.f} : *(const f2*)(uc + cb * 128);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j < 3) {
 #pragma unroll
-        for (int cb = 0; cb < NI; ++cb) wf[(j + 1) & 1][cb] = *(const f2*)(uc + ((j + 1) * NI + cb) * 128);
+        for (int cb = 0; cb < NI; ++cb) wf[(j + 1) & 1][cb] = (dbg & 16) ? (f2){1.f, 1.f} : *(const f2*)(uc + ((j + 1) * NI + cb) * 128);
       }
 #pragma unroll
       for (int cb = 0; cb < NI; ++cb)
@@ -271,14 +276,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int tb = 0; tb < 2; ++tb)
-            acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j & 1][cb][e], V[tb][j][e], acc[j][tb][cb], 0, 0, 0);
+            if (!(dbg & 1)) acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j & 1][cb][e], V[tb][j][e], acc[j][tb][cb], 0, 0, 0);
+            else acc[j][tb][cb][0] += wf[j & 1][cb][e] * V[tb][j][e];
     }
     __builtin_amdgcn_sched_barrier(0);
-    patch_store(nxt);
-    __syncthreads();                    // next chunk's U (LDS-DMA) and patch have landed; everyone is done with `cur`
+    if (!(dbg & 4)) patch_store(nxt);
+    if (!(dbg & 64)) __syncthreads();                    // next chunk's U (LDS-DMA) and patch have landed; everyone is done with `cur`
   }
 
   // ---------------- epilogue: q_b = sum_j M[wave][j] A[j][b]  ->  LDS  ->  Y = sum_i A^T[a][i] q_b
+  if (dbg & 32) { if (acc[0][0][0][0] + acc[1][1][0][1] + acc[3][0][NI - 1][2] == 123.456f) a.out[0] = 1.f; return; }
   float* const Q = smem;                 // [4 waves][2][32 tiles][QLD]  (main-loop LDS is dead: last barrier passed)
 #pragma unroll
   for (int tb = 0; tb < 2; ++tb)
@@ -386,6 +393,8 @@ bool conv_wino_applicable(const ConvArgs& a) {
 // bn: 0 auto | 64 | 32 | 16 output channels per workgroup
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn) {
   if (!conv_wino_applicable(a)) return hipErrorInvalidValue;
+  if (bn == 8) return launch_conv_wino8(a, st);
+  if (bn <= 0 && conv_wino8_applicable(a)) return launch_conv_wino8(a, st);
   if (bn <= 0) {
     bn = a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16);
     // deep, spatially small layers: 64-channel tiles leave half the workgroup slots empty -> 32-channel tiles

@@ -462,7 +462,7 @@ const char* prof_class_name(int cls) {
       "wgrad_patch_kernel<32>",         "wgrad_patch_kernel<64>",         "conv_patch16_kernel<16>",
       "conv_patch16_kernel<32>",        "conv_wino_kernel<64>",           "conv_wino_kernel<32>",
       "conv_wino_kernel<16>",           "wgrad_wino_kernel<64>",          "wgrad_wino_kernel<32>",
-      "wgrad_wino_kernel<16>"};
+      "wgrad_wino_kernel<16>",          "conv_wino8_kernel"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

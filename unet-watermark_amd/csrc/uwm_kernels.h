@@ -63,7 +63,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 25 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16
+enum { kProfClasses = 26 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8
 void prof_enable(bool on);
 bool prof_on();
 void prof_begin(int cls, double flops, hipStream_t st);
@@ -86,7 +86,9 @@ hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);
 hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn);
 // Winograd F(2x2,3x3) (conv_wino.hip): needs a.wu = launch_wino_weights(a.w ...) output; force_cfg 300 (auto tile) / 300+BN
 bool conv_wino_applicable(const ConvArgs& a);
-hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn = 0);
+hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn = 0);   // bn 8 = conv_wino8
+bool conv_wino8_applicable(const ConvArgs& a);              // 512-thread, 16x16-pixel, 64-channel variant (conv_wino8.hip)
+hipError_t launch_conv_wino8(const ConvArgs& a, hipStream_t st);
 size_t wino_weights_floats(int wrows, int Ctot);
 int wino_ncb(int wrows);
 hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, int mirror, float* ut, hipStream_t st);
@@ -95,6 +97,8 @@ struct WinoJobs { WinoJob j[40]; int n; };
 hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st);   // every layer's transform in one launch
 bool winograd_enabled();
 void winograd_enable(bool on);
+void winograd_set_mode(int mode);   // 0 off, 1 auto, 2 = tests: take the 8-wave variant wherever its shape rules allow
+int winograd_mode();
 
 hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st);
 hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,

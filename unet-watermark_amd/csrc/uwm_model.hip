@@ -818,7 +818,7 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st) {
 static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad) {
   return kh == 3 && kw == 3 && stride == 1 && pad == 1 && (a.Ctot & 7) == 0 && (a.C0 & 7) == 0 && a.Ho >= 8 && a.Wo >= 16;
 }
-int uwm_set_winograd(int on) { winograd_enable(on != 0); return 0; }
+int uwm_set_winograd(int on) { winograd_set_mode(on < 0 ? 0 : (on > 2 ? 1 : on)); return 0; }
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }
 
 int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
