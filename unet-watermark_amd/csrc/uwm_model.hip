@@ -406,7 +406,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     for (size_t ci = 0; ci < m->convs.size(); ++ci) {
       const ConvL& cv = m->convs[ci];
-      if (cv.dgrad && !(cv.wud_off && p.wino_ok(ci)))      // Winograd dgrads take their filters from wino_jobs below
+      if (cv.dgrad && (!(cv.wud_off && p.wino_ok(ci)) || cv.CoutP == 16))      // Winograd dgrads take their filters from wino_jobs below; 16-channel dY goes to conv_patch16 (packed bank)
         LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
                                cv.CoutP, m->side));
     }
@@ -500,7 +500,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     } else {
       for (size_t ci = 0; ci < m->convs.size(); ++ci) {
         const ConvL& cv = m->convs[ci];
-        if (cv.dgrad && !(cv.wud_off && p.wino_ok(ci)))
+        if (cv.dgrad && (!(cv.wud_off && p.wino_ok(ci)) || cv.CoutP == 16))
           LCHK(launch_pack_dgrad(m->params + cv.w_off, cv.Cout, cv.Kpad, cv.k * cv.k, cv.CinP, c.F(cv.wd_off), cv.KpadD,
                                  cv.CoutP, st));
       }
