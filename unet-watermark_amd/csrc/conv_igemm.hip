@@ -29,7 +29,10 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.mg);
 }
 
-template <int BM, int BN, int WM, int WN>
+// PC = parity-class launch of a stride-2 dgrad: the workgroups of one launch cover only the output pixels
+// (2i + pc_h, 2j + pc_w) and walk only the taps that reach an input pixel from that class (1, 2, 2 or 4 of the
+// nine; pc_taps lists them) — the plain transposed gather spends 3/4 of its MFMAs on taps its pixels cannot use.
+template <int BM, int BN, int WM, int WN, bool PC = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int MI = BM / WM / 16;      // 16-pixel MFMA tiles per wave
   constexpr int NI = BN / WN / 16;      // 16-channel MFMA tiles per wave
@@ -57,14 +60,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // per staged row: pixel -> (n, ho, wo)
   int rn[XR], rh[XR], rw[XR];
   unsigned rvalid = 0;
-  const int HoWo = a.Ho * a.Wo;
+  const int Wg = PC ? (a.Wo >> 1) : a.Wo;                    // pixel grid this launch walks
+  const int HoWo = PC ? (a.Ho >> 1) * Wg : a.Ho * a.Wo;
+  const int Mg = PC ? a.N * HoWo : a.M;
 #pragma unroll
   for (int i = 0; i < XR; ++i) {
     int m = m0 + r0 + 32 * i;
-    bool v = m < a.M;
+    bool v = m < Mg;
     int mm = v ? m : 0;
     int n = mm / HoWo, rem = mm - n * HoWo;
-    int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    int ho = rem / Wg, wo = rem - ho * Wg;
+    if (PC) { ho = 2 * ho + a.pc_h; wo = 2 * wo + a.pc_w; }
     rn[i] = n; rh[i] = ho * a.smul + a.off; rw[i] = wo * a.smul + a.off;
     rvalid |= (v ? 1u : 0u) << i;
   }
@@ -78,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   f4 xr[XR], wr[WR], tsc, tsh;
   unsigned xvalid = 0; int trelu = 0; bool thas = false;
 
-  auto load_chunk = [&](int kc) {
+  const int cpt = PC ? (a.Ctot >> 5) : 1;                    // PC: 32-float chunks per tap (Ctot % 32 == 0)
+  auto load_chunk = [&](int kci) {
+    int kc = kci;
+    if (PC) { const int ti = kci / cpt; kc = ((a.pc_taps >> (4 * ti)) & 15) * cpt + (kci - ti * cpt); }
     const unsigned k = kc * 32 + unit * 4;
     const unsigned tap = fdiv(k, a.dv_ctot);
     const int c = k - tap * a.Ctot;
@@ -137,9 +146,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   };
 
-  const int nk = a.Kpad >> 5;
-  load_chunk(0);
-  store_chunk(0);
+  const int nk = PC ? a.pc_ntaps * cpt : (a.Kpad >> 5);
+  if (nk > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
@@ -181,11 +192,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   for (int j = 0; j < NI; ++j) { ps[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq[j] = ps[j]; }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + (wm * MI + i) * 16 + lrow;
+    int m = m0 + (wm * MI + i) * 16 + lrow;
+    const bool mv = m < Mg;
+    if (PC && mv) {                                // class-grid index -> real output pixel
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int hi = rem / Wg, wi = rem - hi * Wg;
+      m = (n * a.Ho + 2 * hi + a.pc_h) * a.Wo + 2 * wi + a.pc_w;
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int co = n0 + (wn * NI + j) * 16 + lq * 4;
-      if (m < a.M && co < a.Cout) {
+      if (mv && co < a.Cout) {
         f4 v = acc[i][j];
         const size_t o = (size_t)m * a.Cout + co;
         if (a.bias) v += *(const f4*)(a.bias + co);
@@ -253,6 +270,36 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
   return hipGetLastError();
 }
 
+// stride-2 dgrad as four parity-class launches (see the PC template flag)
+bool conv_s2_dgrad_applicable(const ConvArgs& a) {
+  return a.rmul == -1 && a.sdiv == 2 && a.smul == 1 && (a.ntaps == 9 || a.ntaps == 1) && (a.Ctot & 31) == 0 && a.C0 == a.Ctot &&
+         (a.Ho & 1) == 0 && (a.Wo & 1) == 0 && a.s0.up == 0;
+}
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_s2_dgrad(const ConvArgs& a0, hipStream_t st, int cls) {
+  const int Mg = a0.N * (a0.Ho >> 1) * (a0.Wo >> 1);
+  const int tilesM = (Mg + BM - 1) / BM, tilesN = (a0.Cout + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  for (int pc = 0; pc < 4; ++pc) {
+    ConvArgs a = a0;
+    a.pc_h = pc >> 1; a.pc_w = pc & 1; a.pc_taps = 0; a.pc_ntaps = 0;
+    for (int r = 0; r < a.kw; ++r)
+      for (int s = 0; s < a.kw; ++s)         // tap (r, s) reaches an input pixel iff (ho - r + off) and (wo - s + off) are even
+        if ((((a.pc_h - r + a.off) | (a.pc_w - s + a.off)) & 1) == 0) { a.pc_taps |= (unsigned)(r * a.kw + s) << (4 * a.pc_ntaps); ++a.pc_ntaps; }
+    a.flops = a0.flops * 0.25;
+    if (prof_on()) prof_begin(cls, a.flops, st);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
+    if (prof_on()) prof_end(st);
+  }
+  return hipGetLastError();
+}
+
 static int g_winograd = -1;
 bool winograd_enabled() {
   if (g_winograd < 0) { const char* e = getenv("UWM_WINOGRAD"); g_winograd = (e && e[0] == '0') ? 0 : 1; }
@@ -284,6 +331,8 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
     if (bn == 128 && sp * ((a.Cout + 127) / 128) < 512) bn = 64;
     return launch_conv_patch(a, st, bn);
   }
+  if (cfg < 0 && conv_s2_dgrad_applicable(a))
+    return a.Cout <= 64 ? launch_s2_dgrad<128, 64, 2, 2>(a, st, 1) : launch_s2_dgrad<128, 128, 2, 2>(a, st, 0);
   if (cfg < 0) {
     const long tiles128 = (long)((a.M + 127) / 128);
     if (a.Cout <= 16) cfg = 3;

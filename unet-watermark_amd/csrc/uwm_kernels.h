@@ -43,6 +43,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
+  int pc_h, pc_w, pc_ntaps; unsigned pc_taps;   // stride-2 dgrad parity-class launch (conv_igemm.hip), set by the launcher
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
 };
