@@ -173,6 +173,11 @@ int  uwm_op_maxpool_backward(const float* gout, const uint8_t* idx, const float*
 int  uwm_op_bn_backward(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                         double* scratch2c, float* dy, float* dgamma, float* dbeta, long long npix, int C, uwm_stream stream);
 /* gradient of cat(nearest_x2(prev), skip): gprev[N][H/2][W/2][C0] = mask(sum 2x2 dcat[..., :C0]), gskip = dcat[..., C0:] */
+/* decoder block conv1 dgrad with the concat split fused (Winograd epilogue): gprev [N][H/2][W/2][C0] = ReLU-masked
+ * 2x2 sums of the first C0 gradient channels, gskip [N][H][W][C1] the rest; wd = uwm_op_pack_dgrad output */
+int  uwm_op_dgrad_upsplit(const float* dy, int N, int H, int W, int Cout, const float* wd, int C0, int C1, int KpadD,
+                          float* gprev, const float* pmask, const float* pscale, const float* pshift, float* gskip,
+                          uwm_stream stream);
 int  uwm_op_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev, const float* pmask,
                     const float* pscale, const float* pshift, float* gskip, uwm_stream stream);
 /* out = relu(y*s2+b2 + (sd ? id*sd+bd : id)) */

@@ -338,6 +338,45 @@ def test_upsplit_matches_autograd(cuda):
     assert torch.equal(gs.cpu(), skip.grad.permute(0, 2, 3, 1).contiguous())
 
 
+@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 64, 32), (32, 0, 16), (128, 64, 64)])
+def test_dgrad_with_fused_concat_split(cuda, c0, c1, cout):
+    """decoder conv1 backward: dgrad (Winograd) writes the 2x2-pooled, ReLU-masked gradient of up(prev) and the skip
+    gradient straight from its epilogue — must equal autograd through cat(interpolate(relu(bn(prev))), skip) -> conv."""
+    L = lib()
+    g = torch.Generator().manual_seed(21)
+    n, h, w = 2, 8, 16
+    prev = torch.randn(n, c0, h, w, generator=g, requires_grad=True)
+    sc, sh = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.3
+    a = torch.relu(prev * sc[:, None, None] + sh[:, None, None])
+    a.retain_grad()
+    parts = [F.interpolate(a, scale_factor=2, mode="nearest")]
+    skip = None
+    if c1:
+        skip = torch.randn(n, c1, 2 * h, 2 * w, generator=g, requires_grad=True)
+        parts.append(skip)
+    wt = (torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05)
+    y = F.conv2d(torch.cat(parts, 1), wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ref_prev = (a.grad * (a.detach() > 0)).permute(0, 2, 3, 1)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(cuda)
+    kpadd = rup(9 * cout, 32)
+    wd = torch.empty(c0 + c1, kpadd, device=cuda)
+    L.check(L.lib().uwm_op_pack_dgrad(P(wp), cout, kpad, 9, c0 + c1, P(wd), kpadd, cout, stream()))
+    dyd = nhwc(dy).to(cuda); pm = nhwc(prev.detach()).to(cuda)
+    t = [sc.to(cuda), sh.to(cuda)]
+    gp = torch.full((n, h, w, c0), float("nan"), device=cuda)
+    gs = torch.full((n, 2 * h, 2 * w, max(c1, 4)), float("nan"), device=cuda)
+    L.check(L.lib().uwm_op_dgrad_upsplit(P(dyd), n, 2 * h, 2 * w, cout, P(wd), c0, c1, kpadd, P(gp), P(pm), P(t[0]), P(t[1]),
+                                         P(gs) if c1 else None, stream()))
+    torch.cuda.synchronize()
+    assert (gp.cpu() - ref_prev).abs().max() < 3e-5 * max(1.0, float(ref_prev.abs().max()))
+    if c1:
+        ref_skip = skip.grad.permute(0, 2, 3, 1)
+        assert (gs.cpu() - ref_skip).abs().max() < 3e-5 * max(1.0, float(ref_skip.abs().max()))
+
+
 def test_residual_and_maxpool_backward(cuda):
     L = lib()
     g = torch.Generator().manual_seed(13)

@@ -76,6 +76,7 @@ SIGNATURES = {
     "uwm_op_maxpool": (I, [C.POINTER(uwm_src), I, P, P, P]),
     "uwm_op_maxpool_backward": (I, [P, P, P, C.POINTER(uwm_src), I, P, P]),
     "uwm_op_bn_backward": (I, [P, P, P, P, P, P, P, P, P, L, I, P]),
+    "uwm_op_dgrad_upsplit": (I, [P, I, I, I, I, P, I, I, I, P, P, P, P, P, P]),
     "uwm_op_upsplit": (I, [P, I, I, I, I, I, P, P, P, P, P, P]),
     "uwm_op_residual": (I, [P, P, P, P, P, P, P, L, I, P]),
 }

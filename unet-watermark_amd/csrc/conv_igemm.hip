@@ -319,6 +319,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
             (int)(cfg < 0 && winograd_enabled() && conv_wino_applicable(a)), a.flops * 1e-9);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
+  if (a.out_up) return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;   // fused concat split: Winograd epilogue only
   if (cfg == 200) return launch_conv_patch16(a, st);
   // 16-channel inputs at full resolution are HBM-bound: the one-barrier direct kernel beats the Winograd pipeline there
   if (cfg < 0 && winograd_enabled() && conv_wino_applicable(a) && !conv_patch16_applicable(a)) return launch_conv_wino(a, st);

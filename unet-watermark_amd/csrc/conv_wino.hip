@@ -317,6 +317,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) q[w][b] = *(const f4*)(Q + ((w * 2 + b) * 32 + t) * QLD + cq * 4);
     const int ty = t >> 3, tx = t & 7;
+    if (a.out_up != nullptr) {               // fused concat split of a decoder dgrad (no addend / mask / stats here)
+      const int ho = h0 + 2 * ty, wo = w0 + 2 * tx;
+      if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+        if (co < a.up_c0) {
+          f4 v = q[0][0] + 2.f * q[1][0] - q[3][0] + q[0][1] + 2.f * q[1][1] - q[3][1];       // Y00 + Y10 + Y01 + Y11
+          const size_t o2 = (((size_t)n * (a.Ho >> 1) + (ho >> 1)) * (a.Wo >> 1) + (wo >> 1)) * a.up_c0 + co;
+          if (a.up_mask) {
+            f4 mk = *(const f4*)(a.up_mask + o2);
+            if (a.up_mscale) mk = mk * *(const f4*)(a.up_mscale + co) + *(const f4*)(a.up_mshift + co);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          }
+          *(f4*)(a.out_up + o2) = v;
+        } else {
+          const int c1n = a.Cout - a.up_c0;
+#pragma unroll
+          for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+              const f4 v = ya == 0 ? q[0][xb] + q[1][xb] + q[2][xb] : q[1][xb] - q[2][xb] - q[3][xb];
+              *(f4*)(a.out + (((size_t)n * a.Ho + ho + ya) * a.Wo + wo + xb) * c1n + (co - a.up_c0)) = v;
+            }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int ya = 0; ya < 2; ++ya)
 #pragma unroll
@@ -393,6 +419,9 @@ bool conv_wino_applicable(const ConvArgs& a) {
 // bn: 0 auto | 64 | 32 | 16 output channels per workgroup
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn) {
   if (!conv_wino_applicable(a)) return hipErrorInvalidValue;
+  if (a.out_up && ((a.Ho | a.Wo) & 1 || (a.up_c0 & 3) || a.up_c0 > a.Cout || a.addend || a.mask || a.bias || a.ssum ||
+                   (a.up_c0 < a.Cout && !a.out) || bn == 8))
+    return hipErrorInvalidValue;
   if (bn == 8) return launch_conv_wino8(a, st);
   if (bn <= 0 && conv_wino8_applicable(a)) return launch_conv_wino8(a, st);
   if (bn <= 0) {

@@ -43,6 +43,11 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
+  // decoder dgrad with the concat split fused into the epilogue (conv_wino.hip only): output channels [0, up_c0) are
+  // summed over each 2x2 pixel block (nearest-x2 upsample backward), ReLU-masked by the low-resolution producer
+  // (up_mask * up_mscale + up_mshift > 0) and written to out_up [N][Ho/2][Wo/2][up_c0]; channels [up_c0, Cout) go to
+  // `out` as [N][Ho][Wo][Cout - up_c0] (may be nullptr when there are none)
+  float* out_up; int up_c0; const float* up_mask; const float* up_mscale; const float* up_mshift;
   int pc_h, pc_w, pc_ntaps; unsigned pc_taps;   // stride-2 dgrad parity-class launch (conv_igemm.hip), set by the launcher
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu

@@ -310,9 +310,11 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   return launch_conv(a, c.st, cfg);
 }
 
-// dX = dgrad(dY) (+addend) (*mask)
+struct UpSplit { float* gprev; int C0; const float* pmask; const float* pscale; const float* pshift; };
+// dX = dgrad(dY) (+addend) (*mask); with `us`: decoder concat split fused into the epilogue (dx = gskip or nullptr)
 static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int Wo, int Hin, int Win, float* dx,
-                            const float* addend, const float* mask, const float* mscale, const float* mshift) {
+                            const float* addend, const float* mask, const float* mscale, const float* mshift,
+                            const UpSplit* us = nullptr) {
   const ConvL& cv = c.m->convs[ci];
   ConvArgs a; memset(&a, 0, sizeof(a));
   a.s0 = mk_src(dy, cv.CoutP, Ho, Wo); a.s1 = a.s0; a.C0 = cv.CoutP; a.Ctot = cv.CoutP;
@@ -323,6 +325,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
   if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
+  if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; }
   return launch_conv(a, c.st);
 }
 
@@ -529,10 +532,19 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       Src skip; const Src* sp = nullptr;
       if (i < 3) { skip = feat_src(2 - i); sp = &skip; } else if (i == 3) { skip = f1; sp = &skip; }
       LCHK(run_wgrad(c, dl.c1, prev, sp, c.F(p.g[dl.c1]), h, w));
-      LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, c.F(p.dcat[i]), nullptr, nullptr, nullptr, nullptr));
       float* gprev = (i == 0) ? c.F(p.gx[first_blk[3] + m->stages[3].size() - 1]) : c.F(p.g[m->dec[i - 1].c2]);
-      LCHK(launch_upsplit(c.F(p.dcat[i]), N, h, w, dl.C0, dl.C1, gprev, prev.ptr, prev.scale, prev.shift,
-                          dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, st));
+      const ConvL& c1v = m->convs[dl.c1];
+      if (c1v.wud_off && p.wino_ok((size_t)dl.c1) && !(h & 1) && !(w & 1)) {
+        // Winograd dgrad writes the 2x2-pooled, ReLU-masked gradient of up(prev) and the skip gradient directly:
+        // the full-resolution dcat buffer and the upsplit pass never exist
+        UpSplit us{gprev, dl.C0, prev.ptr, prev.scale, prev.shift};
+        LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, nullptr, nullptr, nullptr,
+                       nullptr, &us));
+      } else {
+        LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, c.F(p.dcat[i]), nullptr, nullptr, nullptr, nullptr));
+        LCHK(launch_upsplit(c.F(p.dcat[i]), N, h, w, dl.C0, dl.C1, gprev, prev.ptr, prev.scale, prev.shift,
+                            dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, st));
+      }
       h /= 2; w /= 2;
     }
   }
@@ -853,6 +865,22 @@ int uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* 
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   if (winograd_enabled() && op_wino_shape(a, kh, kw, stride, pad) && op_wino_prepare(a, 1, (hipStream_t)stream)) return 1;
+  LCHK(launch_conv(a, (hipStream_t)stream));
+  return 0;
+}
+int uwm_op_dgrad_upsplit(const float* dy, int N, int H, int W, int Cout, const float* wd, int C0, int C1, int KpadD,
+                         float* gprev, const float* pmask, const float* pscale, const float* pshift, float* gskip,
+                         uwm_stream stream) {
+  if (!dy || !wd || !gprev || (C1 > 0 && !gskip)) return fail("uwm_op_dgrad_upsplit: null argument");
+  ConvArgs a; memset(&a, 0, sizeof(a));
+  a.s0 = mk_src(dy, Cout, H, W); a.s1 = a.s0; a.C0 = Cout; a.Ctot = Cout;
+  a.w = wd; a.wrows = C0 + C1; a.Kpad = KpadD; a.ntaps = 9; a.kw = 3;
+  a.N = N; a.Ho = H; a.Wo = W; a.Cout = C0 + C1; a.M = N * H * W;
+  a.Hl = H; a.Wl = W; a.smul = 1; a.rmul = -1; a.off = 1; a.sdiv = 1;
+  a.out = gskip; a.out_up = gprev; a.up_c0 = C0; a.up_mask = pmask; a.up_mscale = pscale; a.up_mshift = pshift;
+  a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  if (!op_wino_shape(a, 3, 3, 1, 1) || (H & 1) || (W & 1)) return fail("uwm_op_dgrad_upsplit: needs even H >= 8, W >= 16, channels %% 8 == 0");
+  if (op_wino_prepare(a, 1, (hipStream_t)stream)) return 1;
   LCHK(launch_conv(a, (hipStream_t)stream));
   return 0;
 }
