@@ -69,38 +69,52 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, int wrows, int 
 __global__ void wino_weights_multi_kernel(const WinoJobs jobs) {
   const WinoJob jb = jobs.j[blockIdx.y];
   const int nCb = ((jb.rows + 63) / 64) * 4;
-  const size_t total = (size_t)nCb * 16 * jb.chans;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % jb.chans), row = (int)(i / jb.chans);
-    float g[9];
-    if (jb.mode == 0) {
+  // one thread = one output row x one channel PAIR, rows fastest: a wave writes 512 contiguous bytes per xi
+  const size_t total = (size_t)(jb.chans >> 3) * nCb * 64;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int r16 = (int)(i & 15), lq = (int)((i >> 4) & 3);
+  const int cb = (int)((i >> 6) % nCb), chunk = (int)((i >> 6) / nCb);
+  const int row = cb * 16 + r16, c = chunk * 8 + lq * 2;
+  f2 g[9];
+  if (jb.mode == 0) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = row < jb.rows ? jb.w[(size_t)row * jb.Kpad + (size_t)t * jb.chans + c] : 0.f;
-    } else {
+    for (int t = 0; t < 9; ++t)
+      g[t] = row < jb.rows ? *(const f2*)(jb.w + (size_t)row * jb.Kpad + (size_t)t * jb.chans + c) : (f2){0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = (row < jb.rows && c < jb.src_rows) ? jb.w[(size_t)c * jb.Kpad + (size_t)(8 - t) * jb.rows + row] : 0.f;
+    for (int t = 0; t < 9; ++t) {
+      const size_t o = (size_t)(8 - t) * jb.rows + row;
+      g[t].x = (row < jb.rows && c < jb.src_rows) ? jb.w[(size_t)c * jb.Kpad + o] : 0.f;
+      g[t].y = (row < jb.rows && c + 1 < jb.src_rows) ? jb.w[(size_t)(c + 1) * jb.Kpad + o] : 0.f;
     }
-    float t4[4][3];
+  }
+  f2 t4[4][3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      t4[0][s] = g[s];
-      t4[1][s] = 0.5f * (g[s] + g[3 + s] + g[6 + s]);
-      t4[2][s] = 0.5f * (g[s] - g[3 + s] + g[6 + s]);
-      t4[3][s] = g[6 + s];
-    }
-    const size_t base = ((size_t)(c >> 3) * 16 * nCb + (row >> 4)) * 128 + ((c & 7) >> 1) * 32 + (row & 15) * 2 + (c & 1);
+  for (int s = 0; s < 3; ++s) {
+    t4[0][s] = g[s];
+    t4[1][s] = 0.5f * (g[s] + g[3 + s] + g[6 + s]);
+    t4[2][s] = 0.5f * (g[s] - g[3 + s] + g[6 + s]);
+    t4[3][s] = g[6 + s];
+  }
+  float* const base = jb.ut + ((size_t)chunk * 16 * nCb + cb) * 128 + lq * 32 + r16 * 2;
+  const size_t xs = (size_t)nCb * 128;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      jb.ut[base + (size_t)(r * 4 + 0) * nCb * 128] = t4[r][0];
-      jb.ut[base + (size_t)(r * 4 + 1) * nCb * 128] = 0.5f * (t4[r][0] + t4[r][1] + t4[r][2]);
-      jb.ut[base + (size_t)(r * 4 + 2) * nCb * 128] = 0.5f * (t4[r][0] - t4[r][1] + t4[r][2]);
-      jb.ut[base + (size_t)(r * 4 + 3) * nCb * 128] = t4[r][2];
-    }
+  for (int r = 0; r < 4; ++r) {
+    *(f2*)(base + (size_t)(r * 4 + 0) * xs) = t4[r][0];
+    *(f2*)(base + (size_t)(r * 4 + 1) * xs) = 0.5f * (t4[r][0] + t4[r][1] + t4[r][2]);
+    *(f2*)(base + (size_t)(r * 4 + 2) * xs) = 0.5f * (t4[r][0] - t4[r][1] + t4[r][2]);
+    *(f2*)(base + (size_t)(r * 4 + 3) * xs) = t4[r][2];
   }
 }
 hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st) {
   if (jobs.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(wino_weights_multi_kernel, dim3(64, (unsigned)jobs.n), dim3(256), 0, st, jobs);
+  size_t mx = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    const size_t t = (size_t)(jobs.j[i].chans >> 3) * (((jobs.j[i].rows + 63) / 64) * 4) * 64;
+    if (t > mx) mx = t;
+  }
+  hipLaunchKernelGGL(wino_weights_multi_kernel, dim3((unsigned)((mx + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);
   return hipGetLastError();
 }
 
