@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
   // ---------------- epilogue: lane (p = lane&15 -> pixel, q = lane>>4 -> 4 channels) --------------
   const bool do_stats = a.ssum != nullptr;
+  // BatchNorm statistics go to one of a.srep copies (few-channel layers launch tens of thousands of workgroups:
+  // fp64 atomics on the same 2*C addresses serialise), bn_finalize adds the copies
+  const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
   f4 ps[NI], pq[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) { ps[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq[j] = ps[j]; }
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         double s = 0.0, q = 0.0;
 #pragma unroll
         for (int w = 0; w < WM; ++w) { s += (double)red[(w * BN + tid) * 2]; q += (double)red[(w * BN + tid) * 2 + 1]; }
-        atomicAdd(a.ssum + co, s);
-        atomicAdd(a.ssq + co, q);
+        atomicAdd(a.ssum + srep_off + co, s);
+        atomicAdd(a.ssq + srep_off + co, q);
       }
     }
   }

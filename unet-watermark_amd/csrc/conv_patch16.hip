@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
 
   // ---------------- epilogue (same contract as conv_igemm_kernel) ----------------
   const bool do_stats = a.ssum != nullptr;
+  // BatchNorm statistics go to one of a.srep copies (few-channel layers launch tens of thousands of workgroups:
+  // fp64 atomics on the same 2*C addresses serialise), bn_finalize adds the copies
+  const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
   f4 ps_[NI], pq_[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) { ps_[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq_[j] = ps_[j]; }
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
         double sv = 0.0, qv = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { sv += (double)red[(w * BN + tid) * 2]; qv += (double)red[(w * BN + tid) * 2 + 1]; }
-        atomicAdd(a.ssum + co, sv);
-        atomicAdd(a.ssq + co, qv);
+        atomicAdd(a.ssum + srep_off + co, sv);
+        atomicAdd(a.ssq + srep_off + co, qv);
       }
     }
   }

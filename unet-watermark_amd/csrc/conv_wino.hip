@@ -317,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   constexpr int ITEMS = 32 * CQ / 256;   // (tile, quad) items per thread (BN=64: 2, 32: 1)
   static_assert(32 * CQ % 256 == 0 || 32 * CQ < 256, "item split");
   const bool do_stats = a.ssum != nullptr;
+  // BatchNorm statistics go to one of a.srep copies (few-channel layers launch tens of thousands of workgroups:
+  // fp64 atomics on the same 2*C addresses serialise), bn_finalize adds the copies
+  const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = {0.f, 0.f, 0.f, 0.f};
   const int cq = tid % CQ;
   const int co = n0 + cq * 4;
@@ -396,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
       if (c1 < a.Cout) {
         double sv = 0.0, qv = 0.0;
         for (int g = 0; g < G; ++g) { sv += (double)red[(g * BN + tid) * 2]; qv += (double)red[(g * BN + tid) * 2 + 1]; }
-        atomicAdd(a.ssum + c1, sv);
-        atomicAdd(a.ssq + c1, qv);
+        atomicAdd(a.ssum + srep_off + c1, sv);
+        atomicAdd(a.ssq + srep_off + c1, qv);
       }
     }
   }

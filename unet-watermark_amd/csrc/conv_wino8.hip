@@ -206,6 +206,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino8_kernel(const ConvArgs a) {
   // ---------------- epilogue, one output column parity (b) per pass: q_b -> LDS -> Y[.][b] ----------------
   float* const Q = smem;                 // [4 rows][64 tiles][kQLD8]
   const bool do_stats = a.ssum != nullptr;
+  // BatchNorm statistics go to one of a.srep copies (few-channel layers launch tens of thousands of workgroups:
+  // fp64 atomics on the same 2*C addresses serialise), bn_finalize adds the copies
+  const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = {0.f, 0.f, 0.f, 0.f};
   const int cq = tid & 15;
   const int co = n0 + cq * 4;
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino8_kernel(const ConvArgs a) {
       if (c1 < a.Cout) {
         double sv = 0.0, qv = 0.0;
         for (int g = 0; g < 32; ++g) { sv += (double)red[(g * 64 + tid) * 2]; qv += (double)red[(g * 64 + tid) * 2 + 1]; }
-        atomicAdd(a.ssum + c1, sv);
-        atomicAdd(a.ssq + c1, qv);
+        atomicAdd(a.ssum + srep_off + c1, sv);
+        atomicAdd(a.ssq + srep_off + c1, qv);
       }
     }
   }

@@ -44,11 +44,14 @@ hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, i
 // ------------------------------------------------------------------ BatchNorm finalize
 __global__ void bn_finalize_kernel(const double* ssum, const double* ssq, const float* gamma, const float* beta,
                                    float* run_mean, float* run_var, float* mean, float* rstd, float* scale,
-                                   float* shift, int C, double count, float eps, float momentum, int upd) {
+                                   float* shift, int C, double count, float eps, float momentum, int upd, int nrep,
+                                   int rep_stride) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mu = ssum[c] / count;
-  double var = ssq[c] / count - mu * mu;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrep; ++r) { s1 += ssum[(size_t)r * rep_stride + c]; s2 += ssq[(size_t)r * rep_stride + c]; }
+  const double mu = s1 / count;
+  double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
   const double rs = 1.0 / sqrt(var + (double)eps);
   const float g = gamma[c], b = beta[c];
@@ -63,9 +66,10 @@ __global__ void bn_finalize_kernel(const double* ssum, const double* ssq, const 
 }
 hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,
                               float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
-                              int C, double count, float eps, float momentum, int update_running, hipStream_t st) {
+                              int C, double count, float eps, float momentum, int update_running, hipStream_t st,
+                              int nrep, int rep_stride) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ssum, ssq, gamma, beta, run_mean,
-                     run_var, mean, rstd, scale, shift, C, count, eps, momentum, update_running);
+                     run_var, mean, rstd, scale, shift, C, count, eps, momentum, update_running, nrep < 1 ? 1 : nrep, rep_stride);
   return hipGetLastError();
 }
 

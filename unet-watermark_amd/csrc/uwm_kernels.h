@@ -41,6 +41,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   const float* mask;         // [M][Cout]: out = (mask*mscale+mshift > 0) ? out : 0, or nullptr
   const float* mscale; const float* mshift;
   double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
+  int srep, sstride;         // statistics replicas: workgroup b adds into copy (b & (srep-1)) at +copy*sstride doubles (srep: power of 2, 0/1 = none)
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
   // decoder dgrad with the concat split fused into the epilogue (conv_wino.hip only): output channels [0, up_c0) are
@@ -109,7 +110,8 @@ int winograd_mode();
 hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st);
 hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,
                               float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
-                              int C, double count, float eps, float momentum, int update_running, hipStream_t st);
+                              int C, double count, float eps, float momentum, int update_running, hipStream_t st,
+                              int nrep = 1, int rep_stride = 0);
 hipError_t launch_bn_eval(const float* gamma, const float* beta, const float* run_mean, const float* run_var,
                           float* scale, float* shift, int C, float eps, hipStream_t st);
 // xn = relu(y*s2+b2 + idn), idn = id (materialised) or id*sd+bd (lazy)

@@ -33,7 +33,9 @@ struct BNL {
   std::string name; int C; int stage;
   long long g_off, b_off;          // param arena
   long long rm_off, rv_off;        // buffer arena
-  size_t d_off;                    // workspace doubles: sum, sq, dgamma, dbeta (4*C)
+  size_t d_off;                    // workspace doubles: dgamma[C], dbeta[C], then nrep copies of {sum[C], sq[C]}
+  int nrep;                        // statistics copies (power of 2): spreads the conv epilogues' fp64 atomics
+  size_t dcount() const { return 2 * (size_t)C + (size_t)nrep * 2 * C; }
   size_t f_off;                    // workspace floats: mean, rstd, scale, shift (4*C)
 };
 struct ConvL {
@@ -82,7 +84,7 @@ struct uwm_model {
 };
 
 static int add_bn(uwm_model* m, const std::string& name, int C, int stage) {
-  BNL b; b.name = name; b.C = C; b.stage = stage; b.g_off = b.b_off = b.rm_off = b.rv_off = -1; b.d_off = b.f_off = 0;
+  BNL b; b.name = name; b.C = C; b.stage = stage; b.nrep = C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); b.g_off = b.b_off = b.rm_off = b.rv_off = -1; b.d_off = b.f_off = 0;
   m->bns.push_back(b); return (int)m->bns.size() - 1;
 }
 static int add_conv(uwm_model* m, const std::string& name, int Cin, int Cout, int k, int stride, int pad, int stage,
@@ -168,7 +170,7 @@ static int build_model(uwm_model* m) {
 
   // ---- fixed workspace region: BN scratch, dgrad weight repacks
   size_t dcount = 0;
-  for (auto& b : m->bns) { b.d_off = dcount; dcount += 4 * (size_t)b.C; }
+  for (auto& b : m->bns) { b.d_off = dcount; dcount += b.dcount(); }
   size_t f = dcount * 2;                        // doubles first (in float units)
   f = (size_t)rup((long long)f, 64);
   for (auto& b : m->bns) { b.f_off = f; f += 4 * (size_t)b.C; }
@@ -212,7 +214,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   auto alloc = [&](size_t floats) { size_t o = off; off += (size_t)rup((long long)floats, 64); return o; };
   const size_t nc = m->convs.size();
   p.y.assign(nc, 0); p.g.assign(nc, 0); p.oh.assign(nc, 0); p.ow.assign(nc, 0);
-  p.stat_d = 0; p.stat_d_count = 0; for (auto& b : m->bns) p.stat_d_count += 4 * (size_t)b.C;
+  p.stat_d = 0; p.stat_d_count = 0; for (auto& b : m->bns) p.stat_d_count += b.dcount();
   p.loss_scr = alloc(64);
   p.x4 = alloc((size_t)N * H * W * m->CinP);
   int h = H / 2, w = W / 2;
@@ -303,7 +305,10 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   a.Hl = s0.H << s0.up; a.Wl = s0.W << s0.up;
   a.smul = cv.stride; a.rmul = 1; a.off = -cv.pad; a.sdiv = 1;
   a.out = out; a.bias = cv.bias_off >= 0 ? c.m->params + cv.bias_off : nullptr;
-  if (stats && cv.bn >= 0) { const BNL& b = c.m->bns[cv.bn]; a.ssum = c.D(b.d_off); a.ssq = c.D(b.d_off) + b.C; }
+  if (stats && cv.bn >= 0) {
+    const BNL& b = c.m->bns[cv.bn];
+    a.ssum = c.D(b.d_off) + 2 * b.C; a.ssq = a.ssum + b.C; a.srep = b.nrep; a.sstride = 2 * b.C;
+  }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
   if (cv.wu_off && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout); }
@@ -354,9 +359,9 @@ static hipError_t run_bn_finalize(const Ctx& c, int bi, size_t count, int traini
   uwm_model* m = c.m; const BNL& b = m->bns[bi];
   float* f = c.F(b.f_off);
   if (training)
-    return launch_bn_finalize(c.D(b.d_off), c.D(b.d_off) + b.C, m->params + b.g_off, m->params + b.b_off,
+    return launch_bn_finalize(c.D(b.d_off) + 2 * b.C, c.D(b.d_off) + 3 * b.C, m->params + b.g_off, m->params + b.b_off,
                               m->buffers + b.rm_off, m->buffers + b.rv_off, f, f + b.C, f + 2 * b.C, f + 3 * b.C, b.C,
-                              (double)count, m->desc.bn_eps, m->desc.bn_momentum, 1, c.st);
+                              (double)count, m->desc.bn_eps, m->desc.bn_momentum, 1, c.st, b.nrep, 2 * b.C);
   return launch_bn_eval(m->params + b.g_off, m->params + b.b_off, m->buffers + b.rm_off, m->buffers + b.rv_off,
                         f + 2 * b.C, f + 3 * b.C, b.C, m->desc.bn_eps, c.st);
 }
@@ -365,7 +370,7 @@ static hipError_t run_bn_finalize(const Ctx& c, int bi, size_t count, int traini
 static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, size_t npix) {
   uwm_model* m = c.m; const ConvL& cv = m->convs[ci]; const BNL& b = m->bns[cv.bn];
   const float* f = c.F(b.f_off); const float* y = c.F(m->plan.y[ci]);
-  double* dg = c.D(b.d_off) + 2 * b.C; double* db = c.D(b.d_off) + 3 * b.C;
+  double* dg = c.D(b.d_off); double* db = c.D(b.d_off) + b.C;
   hipError_t e = launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
   if (e != hipSuccess) return e;
   return launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, dg, db, dy, m->grads + b.g_off, m->grads + b.b_off,
