@@ -29,7 +29,7 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.mg);
 }
 
-// PC = parity-class launch of a stride-2 dgrad: the workgroups of one launch cover only the output pixels
+// PC = stride-2 dgrad by output-pixel parity class (blockIdx.y = 2*pc_h + pc_w): a workgroup covers only the pixels
 // (2i + pc_h, 2j + pc_w) and walk only the taps that reach an input pixel from that class (1, 2, 2 or 4 of the
 // nine; pc_taps lists them) — the plain transposed gather spends 3/4 of its MFMAs on taps its pixels cannot use.
 template <int BM, int BN, int WM, int WN, bool PC = false>
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     int mm = v ? m : 0;
     int n = mm / HoWo, rem = mm - n * HoWo;
     int ho = rem / Wg, wo = rem - ho * Wg;
-    if (PC) { ho = 2 * ho + a.pc_h; wo = 2 * wo + a.pc_w; }
+    if (PC) { ho = 2 * ho + (int)(blockIdx.y >> 1); wo = 2 * wo + (int)(blockIdx.y & 1); }
     rn[i] = n; rh[i] = ho * a.smul + a.off; rw[i] = wo * a.smul + a.off;
     rvalid |= (v ? 1u : 0u) << i;
   }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int cpt = PC ? (a.Ctot >> 5) : 1;                    // PC: 32-float chunks per tap (Ctot % 32 == 0)
   auto load_chunk = [&](int kci) {
     int kc = kci;
-    if (PC) { const int ti = kci / cpt; kc = ((a.pc_taps >> (4 * ti)) & 15) * cpt + (kci - ti * cpt); }
+    if (PC) { const int ti = kci / cpt; kc = ((a.pc_taps[blockIdx.y] >> (4 * ti)) & 15) * cpt + (kci - ti * cpt); }
     const unsigned k = kc * 32 + unit * 4;
     const unsigned tap = fdiv(k, a.dv_ctot);
     const int c = k - tap * a.Ctot;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   };
 
-  const int nk = PC ? a.pc_ntaps * cpt : (a.Kpad >> 5);
+  const int nk = PC ? a.pc_ntaps[blockIdx.y] * cpt : (a.Kpad >> 5);
   if (nk > 0) {
     load_chunk(0);
     store_chunk(0);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (PC && mv) {                                // class-grid index -> real output pixel
       const int n = m / HoWo, rem = m - n * HoWo;
       const int hi = rem / Wg, wi = rem - hi * Wg;
-      m = (n * a.Ho + 2 * hi + a.pc_h) * a.Wo + 2 * wi + a.pc_w;
+      m = (n * a.Ho + 2 * hi + (int)(blockIdx.y >> 1)) * a.Wo + 2 * wi + (int)(blockIdx.y & 1);
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -289,17 +289,16 @@ static hipError_t launch_s2_dgrad(const ConvArgs& a0, hipStream_t st, int cls) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  ConvArgs a = a0;
   for (int pc = 0; pc < 4; ++pc) {
-    ConvArgs a = a0;
-    a.pc_h = pc >> 1; a.pc_w = pc & 1; a.pc_taps = 0; a.pc_ntaps = 0;
+    a.pc_taps[pc] = 0; a.pc_ntaps[pc] = 0;
     for (int r = 0; r < a.kw; ++r)
       for (int s = 0; s < a.kw; ++s)         // tap (r, s) reaches an input pixel iff (ho - r + off) and (wo - s + off) are even
-        if ((((a.pc_h - r + a.off) | (a.pc_w - s + a.off)) & 1) == 0) { a.pc_taps |= (unsigned)(r * a.kw + s) << (4 * a.pc_ntaps); ++a.pc_ntaps; }
-    a.flops = a0.flops * 0.25;
-    if (prof_on()) prof_begin(cls, a.flops, st);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
-    if (prof_on()) prof_end(st);
+        if (((((pc >> 1) - r + a.off) | ((pc & 1) - s + a.off)) & 1) == 0) { a.pc_taps[pc] |= (unsigned)(r * a.kw + s) << (4 * a.pc_ntaps[pc]); ++a.pc_ntaps[pc]; }
   }
+  if (prof_on()) prof_begin(cls, a.flops, st);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
+  if (prof_on()) prof_end(st);
   return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   // (up_mask * up_mscale + up_mshift > 0) and written to out_up [N][Ho/2][Wo/2][up_c0]; channels [up_c0, Cout) go to
   // `out` as [N][Ho][Wo][Cout - up_c0] (may be nullptr when there are none)
   float* out_up; int up_c0; const float* up_mask; const float* up_mscale; const float* up_mshift;
-  int pc_h, pc_w, pc_ntaps; unsigned pc_taps;   // stride-2 dgrad parity-class launch (conv_igemm.hip), set by the launcher
+  int pc_ntaps[4]; unsigned pc_taps[4];          // stride-2 dgrad parity classes (conv_igemm.hip; blockIdx.y = class), set by the launcher
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
 };
