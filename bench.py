@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+WINO_RATIO = 2.25            # direct-conv multiplies per Winograd F(2x2,3x3) multiply (36 / 16)
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
 
 
@@ -156,9 +157,13 @@ def main():
         for c in range(ncls):
             cnt, ms, fl = prof[c * 3], prof[c * 3 + 1], prof[c * 3 + 2]
             if cnt > 0:
-                kernels.append({"kernel": L.lib().uwm_prof_class_name(c).decode(), "launches_per_step": cnt / args.steps,
-                                "avg_us": round(1e3 * ms / cnt, 2), "ms_per_step": round(ms / args.steps, 3),
-                                "tflops": round(fl / ms / 1e9, 2)})
+                name = L.lib().uwm_prof_class_name(c).decode()
+                ent = {"kernel": name, "launches_per_step": cnt / args.steps,
+                       "avg_us": round(1e3 * ms / cnt, 2), "ms_per_step": round(ms / args.steps, 3),
+                       "tflops": round(fl / ms / 1e9, 2)}
+                if "wino" in name:      # Winograd F(2x2,3x3): 16 MFMA multiplies per 36 direct ones
+                    ent["mfma_executed_tflops"] = round(fl / ms / 1e9 / WINO_RATIO, 2)
+                kernels.append(ent)
                 tot_ms += ms; tot_fl += fl
         kernels.sort(key=lambda k: -k["ms_per_step"])
         dom = kernels[0] if kernels else None
@@ -183,6 +188,8 @@ def main():
                         cnt, ms, fl = prof_s[c * 3], prof_s[c * 3 + 1], prof_s[c * 3 + 2]
                         serial = {"avg_launch_us": round(1e3 * ms / cnt, 2), "achieved": round(fl / ms / 1e9, 2),
                                   "frac": round(fl / ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                  "mfma_executed_frac": (round(fl / ms / 1e9 / WINO_RATIO / F32_MATRIX_PEAK_TFLOPS, 4)
+                                                         if "wino" in dom["kernel"] else None),
                                   "note": f"{args.serial_steps} extra untimed steps with the wgrad side stream off"}
             traffic = None
             try:   # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
@@ -193,10 +200,16 @@ def main():
                     traffic = {"hbm_bytes_per_launch": ent["hbm_bytes_per_launch"], "source": pm["source"]}
             except Exception:
                 traffic = None
+            wino = "wino" in dom["kernel"]
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                                "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(dom["tflops"] / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
                                "avg_launch_us": dom["avg_us"],
+                               "algorithm": ("Winograd F(2x2,3x3), fp32: `achieved` counts the ALGORITHMIC (direct-convolution) "
+                                             "FLOPs of SURVEY.md 8(d); the kernel executes 1/2.25 of them on the MFMA pipe "
+                                             "(`mfma_executed`), so `frac` may exceed the direct-form ceiling") if wino else "direct",
+                               "mfma_executed": ({"tflops": round(dom["tflops"] / WINO_RATIO, 2),
+                                                  "frac": round(dom["tflops"] / WINO_RATIO / F32_MATRIX_PEAK_TFLOPS, 4)} if wino else None),
                                "note": "launch durations in the timed region include co-residency with kernels of the "
                                        "other stream (wgrad side stream); `unoverlapped` is the same kernel alone",
                                "unoverlapped": serial,

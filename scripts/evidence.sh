@@ -1,0 +1,12 @@
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+T=r01_j
+timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_gpu_tests.log; tail -3 gpurun_out/${T}_gpu_tests.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -o s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${T}_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_fetch/x -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_write/x -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${T}_mfma/x -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_mfma.log 2>&1
+python scripts/pmc_summary.py gpurun_out/${T}_fetch gpurun_out/${T}_write gpurun_out/${T}_mfma ${T} | head -8
+cp profiles/${T}_pmc_summary.json profiles/pmc_traffic.json gpurun_out/
+timeout -k 10 600 python bench.py > gpurun_out/${T}_bench_1gpu.json 2> gpurun_out/${T}_bench.err; tail -c 600 gpurun_out/${T}_bench_1gpu.json
+timeout -k 10 300 python bench_predict.py > gpurun_out/${T}_bench_predict.json 2>/dev/null; tail -c 400 gpurun_out/${T}_bench_predict.json

@@ -19,7 +19,10 @@ for r in csv.DictReader(open(tr)):
     k = norm(r["Kernel_Name"]); dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[k] += 1
 rows, traffic = [], {}
 alias = {"wgrad_patch_kernel<64,32>": "wgrad_patch_kernel<64>", "wgrad_patch_kernel<32,32>": "wgrad_patch_kernel<32>",
-         "wgrad_patch_kernel<16,32>": "wgrad_patch_kernel<16>"}
+         "wgrad_patch_kernel<16,32>": "wgrad_patch_kernel<16>",
+         # template parameter is channel tiles of 16; the profiler class names say channels
+         "conv_wino_kernel<4>": "conv_wino_kernel<64>", "conv_wino_kernel<2>": "conv_wino_kernel<32>",
+         "conv_wino_kernel<1>": "conv_wino_kernel<16>"}
 for k in sorted(dur, key=lambda k: -dur[k])[:16]:
     fe = fa[k].get("FETCH_SIZE", 0) / max(1, fn.get(k, 1)) * 1024; wr = wa[k].get("WRITE_SIZE", 0) / max(1, wn.get(k, 1)) * 1024
     gui = ma[k].get("GRBM_GUI_ACTIVE", 0); busy = ma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
