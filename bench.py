@@ -29,7 +29,7 @@ WINO_RATIO = 2.25            # direct-conv multiplies per Winograd F(2x2,3x3) mu
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
 
 
-def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0):
+def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Unet"):
     """Oracle (torch CPU fp32) train step on a bounded sample: bs2 at the bench resolution."""
     import torch
     from oracle import unet_oracle as O
@@ -43,7 +43,7 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0):
     torch.set_num_threads(cores)
     cores = torch.get_num_threads()
     bs = 2
-    model = O.build(encoder, seed=42)
+    model = O.build(encoder, seed=42, arch=arch)
     model.train()
     crit = O.DiceLoss(smooth=1e-5)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
@@ -55,7 +55,7 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0):
         n += 1
     dt = time.perf_counter() - t0
     return {"value": round(bs * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"Unet-{encoder} {hw}x{hw} bs{bs} fwd+Dice+bwd+Adam on torch-CPU fp32 oracle, 1 warm-up + {n} timed steps"}
+            "sample": f"{arch}-{encoder} {hw}x{hw} bs{bs} fwd+Dice+bwd+Adam on torch-CPU fp32 oracle, 1 warm-up + {n} timed steps"}
 
 
 def main():
@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--encoder", default="resnet34")
+    ap.add_argument("--arch", default="Unet", choices=["Unet", "UnetPlusPlus"],
+                    help="Unet = BASELINE.json's configs (headline); UnetPlusPlus = the reference's default MODEL.NAME (SURVEY 8 f3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
     ap.add_argument("--serial-steps", type=int, default=3,
@@ -98,7 +100,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     torch.manual_seed(42)                                  # identical init on every rank (+ broadcast in Trainer)
-    model = U.Unet(args.encoder, encoder_weights=None, in_channels=3, classes=1).to(dev)
+    model = getattr(U, args.arch)(args.encoder, encoder_weights=None, in_channels=3, classes=1).to(dev)
     trainer = Trainer(model, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-4, weight_decay=1e-4,
                       overlap_comm=not args.no_overlap, force_ddp=force_ddp)
     g = torch.Generator(device="cpu").manual_seed(42 + rank)      # rank-distinct synthetic data
@@ -151,7 +153,7 @@ def main():
 
     if rank == 0:
         from oracle.unet_oracle import conv_flops
-        fwd, fwdbwd = conv_flops(args.encoder, s, s)
+        fwd, fwdbwd = conv_flops(args.encoder, s, s, arch=args.arch)
         kernels = []
         tot_ms = tot_fl = 0.0
         for c in range(ncls):
@@ -172,8 +174,9 @@ def main():
             "metric": "train_images_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Unet-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
-                                   f"(BASELINE.json configs[{1 if world == 1 else 2}])",
+            "config": {"workload": f"{args.arch}-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
+                                   + (f"(BASELINE.json configs[{1 if world == 1 else 2}])" if args.arch == "Unet" else
+                                      "(not a BASELINE config: SURVEY 8 f3 widening)"),
                        "global_batch": world * n, "image": [s, s], "parallelism": f"dp{world}",
                        "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if (world > 1 or force_ddp) else "none")},
             "loss": round(loss_val, 6),
@@ -217,7 +220,7 @@ def main():
                                                     "frac": round(tot_fl / tot_ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
                                                     "share_of_step": round(tot_ms / args.steps / ms_step, 4)}}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.encoder, s)
+            out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch)
         print(json.dumps(out), flush=True)
     if world > 1 or force_ddp:
         dist.barrier(device_ids=[local_rank])

@@ -38,6 +38,7 @@ typedef struct uwm_model* uwm_handle;
 typedef void* uwm_stream;              /* hipStream_t */
 
 enum { UWM_ENC_RESNET18 = 18, UWM_ENC_RESNET34 = 34 };
+enum { UWM_ARCH_UNET = 0, UWM_ARCH_UNETPLUSPLUS = 1 };   /* smp.Unet | smp.UnetPlusPlus (the reference's default MODEL.NAME, src/configs/config.py:15) */
 enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* target dtypes */
 enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
        UWM_KIND_BN_MEAN = 4, UWM_KIND_BN_VAR = 5 };
@@ -51,6 +52,7 @@ typedef struct {
   int decoder_channels[5];     /* e.g. 256,128,64,32,16 ; each a multiple of 4 */
   float bn_eps;                /* 1e-5 */
   float bn_momentum;           /* 0.1 */
+  int arch;                    /* UWM_ARCH_* ; decoder of src/models/unet_model.py:19 (create_model_from_config) */
 } uwm_unet_desc;
 
 typedef struct {

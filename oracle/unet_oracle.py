@@ -137,9 +137,63 @@ class UnetDecoder(nn.Module):
         return x
 
 
+class UnetPlusPlusDecoder(nn.Module):
+    """smp.decoders.unetplusplus.decoder.UnetPlusPlusDecoder (attention None, center False): dense grid of the
+    same DecoderBlocks, keyed x_{depth}_{layer} in a ModuleDict (state_dict keys `decoder.blocks.x_0_0.conv1.0.weight`
+    ...).  [smp-knowledge; source not in the container — SURVEY.md Appendix A]  It is what the reference builds by
+    default: MODEL.NAME = "UnetPlusPlus" (/root/reference/src/configs/config.py:15, src/models/unet_model.py:19)."""
+
+    def __init__(self, encoder_channels, decoder_channels):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]          # (512,256,128,64,64)
+        self.in_channels = [enc[0]] + list(decoder_channels[:-1])
+        self.skip_channels = enc[1:] + [0]
+        self.out_channels = list(decoder_channels)
+        blocks = {}
+        for layer_idx in range(len(self.in_channels) - 1):
+            for depth_idx in range(layer_idx + 1):
+                if depth_idx == 0:
+                    in_ch = self.in_channels[layer_idx]
+                    skip_ch = self.skip_channels[layer_idx] * (layer_idx + 1)
+                    out_ch = self.out_channels[layer_idx]
+                else:
+                    out_ch = self.skip_channels[layer_idx]
+                    skip_ch = self.skip_channels[layer_idx] * (layer_idx + 1 - depth_idx)
+                    in_ch = self.skip_channels[layer_idx - 1]
+                blocks[f"x_{depth_idx}_{layer_idx}"] = DecoderBlock(in_ch, skip_ch, out_ch)
+        blocks[f"x_{0}_{len(self.in_channels) - 1}"] = DecoderBlock(self.in_channels[-1], 0, self.out_channels[-1])
+        self.blocks = nn.ModuleDict(blocks)
+        self.depth = len(self.in_channels) - 1
+        for m in self.modules():                         # smp initialize_decoder
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, *features):
+        features = features[1:][::-1]
+        dense_x = {}
+        for layer_idx in range(len(self.in_channels) - 1):
+            for depth_idx in range(self.depth - layer_idx):
+                if layer_idx == 0:
+                    output = self.blocks[f"x_{depth_idx}_{depth_idx}"](features[depth_idx], features[depth_idx + 1])
+                    dense_x[f"x_{depth_idx}_{depth_idx}"] = output
+                else:
+                    dense_l_i = depth_idx + layer_idx
+                    cat_features = [dense_x[f"x_{idx}_{dense_l_i}"] for idx in range(depth_idx + 1, dense_l_i + 1)]
+                    cat_features = torch.cat(cat_features + [features[dense_l_i + 1]], dim=1)
+                    dense_x[f"x_{depth_idx}_{dense_l_i}"] = self.blocks[f"x_{depth_idx}_{dense_l_i}"](
+                        dense_x[f"x_{depth_idx}_{dense_l_i - 1}"], cat_features)
+        dense_x[f"x_{0}_{self.depth}"] = self.blocks[f"x_{0}_{self.depth}"](dense_x[f"x_{0}_{self.depth - 1}"])
+        return dense_x[f"x_{0}_{self.depth}"]
+
+
 class OracleUnet(nn.Module):
     """smp.Unet(encoder_name, encoder_depth=5, encoder_weights=None, decoder_channels,
     in_channels, classes, activation=None) — SURVEY.md Appendix A.1-A.4."""
+
+    _DECODER = UnetDecoder
 
     def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None,
                  decoder_use_batchnorm=True, decoder_channels=(256, 128, 64, 32, 16),
@@ -154,7 +208,7 @@ class OracleUnet(nn.Module):
                 or activation is not None or aux_params is not None or not decoder_use_batchnorm:
             raise ValueError("oracle: unsupported option")
         self.encoder = ResNetEncoder(encoder_name, in_channels)
-        self.decoder = UnetDecoder(self.encoder.out_channels, tuple(decoder_channels))
+        self.decoder = self._DECODER(self.encoder.out_channels, tuple(decoder_channels))
         head = nn.Conv2d(decoder_channels[-1], classes, 3, 1, 1)
         nn.init.xavier_uniform_(head.weight)             # smp initialize_head
         nn.init.constant_(head.bias, 0)
@@ -167,6 +221,11 @@ class OracleUnet(nn.Module):
                 f"Wrong input shape height={h}, width={w}. Expected image height and width "
                 f"divisible by 32.")
         return self.segmentation_head(self.decoder(*self.encoder(x)))
+
+
+class OracleUnetPlusPlus(OracleUnet):
+    """smp.UnetPlusPlus(...) with the same constructor surface: only the decoder differs."""
+    _DECODER = UnetPlusPlusDecoder
 
 
 # ----------------------------------------------------------------------------- losses
@@ -271,9 +330,9 @@ def synthetic_batch(n: int, h: int, w: int, seed: int = 42, in_channels: int = 3
     return x, t
 
 
-def build(encoder_name="resnet34", seed=42, **kw) -> OracleUnet:
+def build(encoder_name="resnet34", seed=42, arch="Unet", **kw) -> OracleUnet:
     torch.manual_seed(seed)
-    return OracleUnet(encoder_name=encoder_name, **kw)
+    return {"Unet": OracleUnet, "UnetPlusPlus": OracleUnetPlusPlus}[arch](encoder_name=encoder_name, **kw)
 
 
 def train_step(model, criterion, optimizer, images, masks):
@@ -289,7 +348,7 @@ def train_step(model, criterion, optimizer, images, masks):
 
 
 def conv_flops(encoder_name="resnet34", h=512, w=512, decoder_channels=(256, 128, 64, 32, 16),
-               in_channels=3, classes=1):
+               in_channels=3, classes=1, arch="Unet"):
     """Algorithmic conv FLOPs per image: (fwd, fwd+bwd) — SURVEY.md §8(d)."""
     macs = []          # (macs, needs_dgrad)
     def conv(cin, cout, k, ho, wo, dgrad=True):
@@ -308,10 +367,24 @@ def conv_flops(encoder_name="resnet34", h=512, w=512, decoder_channels=(256, 128
     enc = [512, 256, 128, 64, 64]
     in_ch = [enc[0]] + list(decoder_channels[:-1])
     skip = enc[1:] + [0]
-    for i, s, o in zip(in_ch, skip, decoder_channels):
-        hh, ww = hh * 2, ww * 2
-        conv(i + s, o, 3, hh, ww)
-        conv(o, o, 3, hh, ww)
+    if arch == "Unet":
+        for i, s, o in zip(in_ch, skip, decoder_channels):
+            hh, ww = hh * 2, ww * 2
+            conv(i + s, o, 3, hh, ww)
+            conv(o, o, 3, hh, ww)
+    else:                                   # UnetPlusPlus: block x_{d}_{L} runs at 1/2^(4-L) resolution
+        for lay in range(4):
+            for dep in range(lay + 1):
+                if dep == 0:
+                    ci, cs, co = in_ch[lay], skip[lay] * (lay + 1), decoder_channels[lay]
+                else:
+                    ci, cs, co = skip[lay - 1], skip[lay] * (lay + 1 - dep), skip[lay]
+                bh, bw = h >> (4 - lay), w >> (4 - lay)
+                conv(ci + cs, co, 3, bh, bw)
+                conv(co, co, 3, bh, bw)
+        conv(in_ch[4], decoder_channels[4], 3, h, w)
+        conv(decoder_channels[4], decoder_channels[4], 3, h, w)
+        hh, ww = h, w
     conv(decoder_channels[-1], classes, 3, hh, ww)
     fwd = 2 * sum(m for m, _ in macs)
     bwd = 2 * sum(m * (2 if d else 1) for m, d in macs)

@@ -9,11 +9,11 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
 
 
-def _pair(enc, seed=42, dev=None, **kw):
+def _pair(enc, seed=42, dev=None, arch="Unet", **kw):
     import unet_watermark_amd as U
     from oracle import unet_oracle as O
-    ref = O.build(enc, seed=seed, **kw)
-    m = U.Unet(enc, **kw).to(dev)
+    ref = O.build(enc, seed=seed, arch=arch, **kw)
+    m = getattr(U, arch)(enc, **kw).to(dev)
     m.load_state_dict(ref.state_dict())
     return m, ref
 
@@ -85,6 +85,48 @@ def test_train_forward_backward_parity(cuda, enc, n, h, w):
     for v in m._grad_views:
         v.zero_()               # every logical element of the arena
     assert float(m.flat_grads().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("enc,n,h,w", [("resnet18", 4, 128, 160), ("resnet34", 2, 256, 192), ("resnet18", 4, 64, 64)])
+def test_unetplusplus_train_forward_backward_parity(cuda, enc, n, h, w):
+    """UnetPlusPlus (the reference's default MODEL.NAME): dense decoder grid, several consumers per tensor in the
+    backward (write-then-accumulate gradient buffers), both the fused Winograd concat split and the dcat fallback
+    (the 64x64 case puts most nodes below the Winograd tile size)."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    m, ref = _pair(enc, dev=cuda, arch="UnetPlusPlus")
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for p in ref.parameters())
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    x, t = O.synthetic_batch(n, h, w, seed=9)
+    m.train(); ref.train()
+    crit_ref = O.CombinedLoss([O.BCEWithLogits(), O.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    crit = U.CombinedLoss([U.BCEWithLogitsLoss(), U.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    out_ref = ref(x); loss_ref = crit_ref(out_ref, t.unsqueeze(1)); loss_ref.backward()
+    out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda)); loss.backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    _grad_check(m, ref)
+    # eval mode (running statistics) after the same training forward on both sides
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert (m(x.to(cuda)).cpu() - ref(x)).abs().max() < LOGIT_TOL
+
+
+def test_unetplusplus_trainer_steps_match_oracle(cuda):
+    """three fused Trainer steps (forward, Dice, staged backward, Adam) of UnetPlusPlus track the oracle's."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd.train import Trainer
+    from oracle import unet_oracle as O
+    m, ref = _pair("resnet18", dev=cuda, arch="UnetPlusPlus")
+    x, t = O.synthetic_batch(4, 128, 128, seed=5)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, eps=1e-2)
+    tr = Trainer(m, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-3, adam_eps=1e-2)
+    crit = O.DiceLoss(smooth=1e-5)
+    ref.train()
+    for step in range(3):
+        _, lr_ = O.train_step(ref, crit, opt, x, t)
+        l = tr.step(x.to(cuda), t.to(cuda))
+        assert abs(float(l[0]) - float(lr_)) < 2e-4, (step, float(l[0]), float(lr_))
 
 
 def test_eval_forward_and_batch_independence(cuda):

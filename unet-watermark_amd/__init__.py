@@ -5,7 +5,7 @@ Python host layer over libuwm.so (hand-written HIP for gfx950, C ABI in include/
 Import name: `unet_watermark_amd` (alias package next to this directory).
 """
 from . import _lib  # noqa: F401
-from .model import Unet, create_model, create_model_from_config, SUPPORTED_MODELS  # noqa: F401
+from .model import Unet, UnetPlusPlus, create_model, create_model_from_config, SUPPORTED_MODELS  # noqa: F401
 from .losses import DiceLoss, BCEWithLogitsLoss, CombinedLoss, get_loss_function  # noqa: F401
 from .metrics import get_metrics, get_stats, micro_scores, logits_metrics, threshold_mask, resize_threshold  # noqa: F401
 

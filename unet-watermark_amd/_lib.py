@@ -20,7 +20,7 @@ HIP_ARCH = "gfx950"
 
 class uwm_unet_desc(C.Structure):
     _fields_ = [("encoder", C.c_int), ("in_channels", C.c_int), ("classes", C.c_int),
-                ("decoder_channels", C.c_int * 5), ("bn_eps", C.c_float), ("bn_momentum", C.c_float)]
+                ("decoder_channels", C.c_int * 5), ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("arch", C.c_int)]
 
 
 class uwm_tensor_info(C.Structure):
@@ -36,6 +36,7 @@ class uwm_src(C.Structure):
 KIND_CONV_W, KIND_BIAS, KIND_BN_GAMMA, KIND_BN_BETA, KIND_BN_MEAN, KIND_BN_VAR = range(6)
 ARENA_PARAM, ARENA_BUFFER = 0, 1
 ENC = {"resnet18": 18, "resnet34": 34}
+ARCH = {"Unet": 0, "UnetPlusPlus": 1}
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 # every symbol include/uwm.h declares: (restype, argtypes)

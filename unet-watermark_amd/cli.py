@@ -78,8 +78,10 @@ def train_command(args):
         cfg.TRAIN.USE_EARLY_STOPPING = False
     if args.encoder:
         cfg.MODEL.ENCODER_NAME = args.encoder
-    if cfg.MODEL.NAME != "Unet":
-        raise ValueError(f"MODEL.NAME={cfg.MODEL.NAME!r}: this build serves 'Unet' only")
+    if getattr(args, "model", None):
+        cfg.MODEL.NAME = args.model
+    if cfg.MODEL.NAME not in ("Unet", "UnetPlusPlus"):
+        raise ValueError(f"MODEL.NAME={cfg.MODEL.NAME!r}: this build serves 'Unet' and 'UnetPlusPlus'")
     if cfg.MODEL.ENCODER_WEIGHTS is not None:
         print(f"note: ENCODER_WEIGHTS={cfg.MODEL.ENCODER_WEIGHTS!r} needs a download; training from seeded init")
         cfg.MODEL.ENCODER_WEIGHTS = None
@@ -191,6 +193,7 @@ def main(argv=None):
     tp.add_argument("--encoder", type=str); tp.add_argument("--img-size", type=int)
     tp.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of DATA.ROOT_DIR")
     tp.add_argument("--workers", type=int, default=2)
+    tp.add_argument("--model", choices=["Unet", "UnetPlusPlus"], default=None, help="MODEL.NAME (reference default: UnetPlusPlus)")
     tp.add_argument("--grad-clip", action="store_true", help="honour TRAIN.GRADIENT_CLIP (the reference defines but never applies it)")
     pp = sub.add_parser("predict")
     pp.add_argument("--input", type=str, required=True); pp.add_argument("--output", type=str, required=True)

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
             v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
           }
+          if (a.up_accum) v += *(const f4*)(a.out_up + o2);
           *(f4*)(a.out_up + o2) = v;
         } else {
           const int c1n = a.Cout - a.up_c0;

@@ -271,7 +271,7 @@ hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean
 // ------------------------------------------------------------------ upsample+concat gradient split
 __global__ void upsplit_prev_kernel(const float* __restrict__ dcat, int H, int W, int C0, int Ct, float* __restrict__ gprev,
                                     const float* __restrict__ pmask, const float* __restrict__ pscale,
-                                    const float* __restrict__ pshift, size_t total) {
+                                    const float* __restrict__ pshift, size_t total, int accumulate) {
   const int C4 = C0 / 4, H2 = H / 2, W2 = W / 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
@@ -285,6 +285,7 @@ __global__ void upsplit_prev_kernel(const float* __restrict__ dcat, int H, int W
       if (pscale) z = z * *(const f4*)(pscale + c) + *(const f4*)(pshift + c);
       g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
     }
+    if (accumulate) g += *(const f4*)(gprev + i * 4);
     *(f4*)(gprev + i * 4) = g;
   }
 }
@@ -297,14 +298,65 @@ __global__ void upsplit_skip_kernel(const float* __restrict__ dcat, int C0, int 
   }
 }
 hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev, const float* pmask,
-                          const float* pscale, const float* pshift, float* gskip, hipStream_t st) {
+                          const float* pscale, const float* pshift, float* gskip, hipStream_t st, int accumulate_prev) {
   const size_t t0 = (size_t)N * (H / 2) * (W / 2) * (C0 / 4);
   hipLaunchKernelGGL(upsplit_prev_kernel, dim3(nblocks(t0, 256)), dim3(256), 0, st, dcat, H, W, C0, C0 + C1, gprev, pmask,
-                     pscale, pshift, t0);
+                     pscale, pshift, t0, accumulate_prev);
   if (C1 > 0 && gskip) {
     const size_t t1 = (size_t)N * H * W * (C1 / 4);
     hipLaunchKernelGGL(upsplit_skip_kernel, dim3(nblocks(t1, 256)), dim3(256), 0, st, dcat, C0, C1, gskip, t1);
   }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ UNet++ dense skip plumbing
+// dst[pix][dst_off + c] = act(src[pix][c])   (act = lazy BatchNorm scale/shift + ReLU of the producer, or identity)
+__global__ void concat_copy_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, int relu, int C, float* __restrict__ dst, int Cd,
+                                   int dst_off, size_t total) {
+  const int C4 = C / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const size_t p = i / C4;
+    f4 v = *(const f4*)(src + p * C + c);
+    if (scale) {
+      v = v * *(const f4*)(scale + c) + *(const f4*)(shift + c);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    *(f4*)(dst + p * Cd + dst_off + c) = v;
+  }
+}
+hipError_t launch_concat_copy(const Src& s, size_t npix, float* dst, int Cd, int dst_off, hipStream_t st) {
+  const size_t total = npix * (size_t)(s.C / 4);
+  hipLaunchKernelGGL(concat_copy_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, s.ptr, s.scale, s.shift, s.relu, s.C, dst,
+                     Cd, dst_off, total);
+  return hipGetLastError();
+}
+// dst[pix][c] (+)= mask * gcat[pix][off + c],  mask = (m[pix][c]*mscale[c]+mshift[c] > 0) of the tensor the
+// gradient belongs to (nullptr: no mask — the consumer applies its own)
+__global__ void split_accum_kernel(const float* __restrict__ gcat, int Cc, int off, int C, float* __restrict__ dst,
+                                   const float* __restrict__ m, const float* __restrict__ mscale,
+                                   const float* __restrict__ mshift, int accumulate, size_t total) {
+  const int C4 = C / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const size_t p = i / C4;
+    f4 g = *(const f4*)(gcat + p * Cc + off + c);
+    if (m) {
+      f4 z = *(const f4*)(m + p * C + c);
+      if (mscale) z = z * *(const f4*)(mscale + c) + *(const f4*)(mshift + c);
+      g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+    }
+    float* d = dst + p * C + c;
+    if (accumulate) g += *(const f4*)d;
+    *(f4*)d = g;
+  }
+}
+hipError_t launch_split_accum(const float* gcat, int Cc, int off, int C, size_t npix, float* dst, const float* m,
+                              const float* mscale, const float* mshift, int accumulate, hipStream_t st) {
+  const size_t total = npix * (size_t)(C / 4);
+  hipLaunchKernelGGL(split_accum_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, gcat, Cc, off, C, dst, m, mscale, mshift,
+                     accumulate, total);
   return hipGetLastError();
 }
 

@@ -49,6 +49,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   // (up_mask * up_mscale + up_mshift > 0) and written to out_up [N][Ho/2][Wo/2][up_c0]; channels [up_c0, Cout) go to
   // `out` as [N][Ho][Wo][Cout - up_c0] (may be nullptr when there are none)
   float* out_up; int up_c0; const float* up_mask; const float* up_mscale; const float* up_mshift;
+  int up_accum;              // out_up += instead of = (a tensor with several consumers: UNet++)
   int pc_ntaps[4]; unsigned pc_taps[4];          // stride-2 dgrad parity classes (conv_igemm.hip; blockIdx.y = class), set by the launcher
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
@@ -130,7 +131,12 @@ hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean
 // dcat [N][H][W][C0+C1] -> gprev [N][H/2][W/2][C0] = mask(sum 2x2), gskip [N][H][W][C1] (copy)
 hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev,
                           const float* pmask, const float* pscale, const float* pshift, float* gskip,
-                          hipStream_t st);
+                          hipStream_t st, int accumulate_prev = 0);
+// UNet++ dense skips: materialise act(src) into a channel range of a concat buffer / scatter-accumulate a channel
+// range of a concat gradient back (optionally ReLU-masked by the tensor it belongs to)
+hipError_t launch_concat_copy(const Src& s, size_t npix, float* dst, int Cd, int dst_off, hipStream_t st);
+hipError_t launch_split_accum(const float* gcat, int Cc, int off, int C, size_t npix, float* dst, const float* m,
+                              const float* mscale, const float* mshift, int accumulate, hipStream_t st);
 hipError_t launch_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD,
                              int CoutP, hipStream_t st);
 hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double* scratch, hipStream_t st);

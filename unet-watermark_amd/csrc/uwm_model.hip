@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 using namespace uwm;
 
@@ -48,6 +49,9 @@ struct ConvL {
 };
 struct BlockL { int c1, c2, cd; };
 struct DecL { int c1, c2, C0, C1; };
+// UnetPlusPlus decoder block.  Tensor ids: 0..4 = encoder features f1..f5 (f1 = stem, f5 = deepest), 5 + i = output
+// of node i.  lvl = log2 of the down-scale of the node's OUTPUT (f1: 1 ... f5: 5, final node: 0).
+struct NodeL { int c1, c2, prev; std::vector<int> skips; int C0, C1, lvl; };
 
 struct Plan {                       // workspace layout for one (N,H,W,training)
   int N = 0, H = 0, W = 0, training = -1;
@@ -57,7 +61,9 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   std::vector<int> oh, ow;          // per conv: output height / width
   bool wino_ok(size_t ci) const { return winograd_enabled() && oh[ci] >= 8 && ow[ci] >= 16; }   // conv_wino tile fits
   std::vector<size_t> xn, gx;       // per encoder block: residual output / its gradient
-  std::vector<size_t> dcat, gskip;  // per decoder block
+  std::vector<size_t> dcat, gskip;  // per decoder block (UnetPlusPlus: dcat[0] = shared scratch, gskip[0..3] = f4,f3,f2,f1 accumulators)
+  std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
+  size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
 };
 
@@ -67,6 +73,7 @@ struct uwm_model {
   std::vector<BNL> bns;
   std::vector<std::vector<BlockL>> stages;   // 4 encoder stages
   std::vector<DecL> dec;
+  std::vector<NodeL> nodes;          // UnetPlusPlus (arch 1) decoder in forward order; empty for Unet
   int stem = -1, head = -1, CP = 4, CinP = 4;
   long long param_floats = 0, buffer_floats = 0, param_count = 0;
   long long stage_begin[6] = {0, 0, 0, 0, 0, 0};
@@ -140,15 +147,54 @@ static int build_model(uwm_model* m) {
   }
   const int encc[5] = {512, 256, 128, 64, 64};
   int prev = encc[0];
-  for (int i = 0; i < 5; ++i) {
-    const int skip = i < 4 ? encc[i + 1] : 0, out = d.decoder_channels[i];
-    char pre[64]; snprintf(pre, sizeof(pre), "decoder.blocks.%d", i);
-    DecL dl; dl.C0 = prev; dl.C1 = skip;
-    dl.c1 = add_conv(m, std::string(pre) + ".conv1.0", prev + skip, out, 3, 1, 1, 0, true, std::string(pre) + ".conv1.1");
-    dl.c2 = add_conv(m, std::string(pre) + ".conv2.0", out, out, 3, 1, 1, 0, true, std::string(pre) + ".conv2.1");
-    m->dec.push_back(dl);
-    prev = out;
-  }
+  if (d.arch == UWM_ARCH_UNET) {
+    for (int i = 0; i < 5; ++i) {
+      const int skip = i < 4 ? encc[i + 1] : 0, out = d.decoder_channels[i];
+      char pre[64]; snprintf(pre, sizeof(pre), "decoder.blocks.%d", i);
+      DecL dl; dl.C0 = prev; dl.C1 = skip;
+      dl.c1 = add_conv(m, std::string(pre) + ".conv1.0", prev + skip, out, 3, 1, 1, 0, true, std::string(pre) + ".conv1.1");
+      dl.c2 = add_conv(m, std::string(pre) + ".conv2.0", out, out, 3, 1, 1, 0, true, std::string(pre) + ".conv2.1");
+      m->dec.push_back(dl);
+      prev = out;
+    }
+  } else if (d.arch == UWM_ARCH_UNETPLUSPLUS) {
+    // smp UnetPlusPlusDecoder (SURVEY.md App. A / oracle/unet_oracle.py OracleUnetPlusPlus): blocks x_{depth}_{layer}
+    const int in_ch[5] = {encc[0], d.decoder_channels[0], d.decoder_channels[1], d.decoder_channels[2], d.decoder_channels[3]};
+    const int skip_ch[5] = {encc[1], encc[2], encc[3], encc[4], 0};
+    int blk_c1[5][5], blk_c2[5][5], blk_in[5][5], blk_skip[5][5];
+    auto add_block = [&](int dep, int lay, int cin_, int cskip, int cout_) {
+      char pre[64]; snprintf(pre, sizeof(pre), "decoder.blocks.x_%d_%d", dep, lay);
+      blk_in[dep][lay] = cin_; blk_skip[dep][lay] = cskip;
+      blk_c1[dep][lay] = add_conv(m, std::string(pre) + ".conv1.0", cin_ + cskip, cout_, 3, 1, 1, 0, true, std::string(pre) + ".conv1.1");
+      blk_c2[dep][lay] = add_conv(m, std::string(pre) + ".conv2.0", cout_, cout_, 3, 1, 1, 0, true, std::string(pre) + ".conv2.1");
+    };
+    for (int lay = 0; lay < 4; ++lay)            // registration order of smp's ModuleDict = state_dict order
+      for (int dep = 0; dep <= lay; ++dep) {
+        if (dep == 0) add_block(0, lay, in_ch[lay], skip_ch[lay] * (lay + 1), d.decoder_channels[lay]);
+        else add_block(dep, lay, skip_ch[lay - 1], skip_ch[lay] * (lay + 1 - dep), skip_ch[lay]);
+      }
+    add_block(0, 4, in_ch[4], 0, d.decoder_channels[4]);
+    // forward order (smp UnetPlusPlusDecoder.forward); features[k] = f_{5-k} = tensor id 4 - k
+    int node_of[5][5];
+    auto add_node = [&](int dep, int lay, int prev_id, const std::vector<int>& skips, int lvl) {
+      NodeL nd; nd.c1 = blk_c1[dep][lay]; nd.c2 = blk_c2[dep][lay]; nd.prev = prev_id; nd.skips = skips;
+      nd.C0 = blk_in[dep][lay]; nd.C1 = blk_skip[dep][lay]; nd.lvl = lvl;
+      node_of[dep][lay] = (int)m->nodes.size(); m->nodes.push_back(nd);
+    };
+    for (int li = 0; li < 4; ++li)
+      for (int dep = 0; dep < 4 - li; ++dep) {
+        if (li == 0) add_node(dep, dep, 4 - dep, {4 - (dep + 1)}, 4 - dep);
+        else {
+          const int L2 = dep + li;
+          std::vector<int> sk;
+          for (int idx = dep + 1; idx <= L2; ++idx) sk.push_back(5 + node_of[idx][L2]);
+          sk.push_back(4 - (L2 + 1));
+          add_node(dep, L2, 5 + node_of[dep][L2 - 1], sk, 4 - L2);
+        }
+      }
+    add_node(0, 4, 5 + node_of[0][3], {}, 0);
+    prev = d.decoder_channels[4];
+  } else return fail("unsupported architecture %d (0 = Unet, 1 = UnetPlusPlus)", d.arch);
   m->head = add_conv(m, "segmentation_head.0", prev, d.classes, 3, 1, 1, 0, true, "", true);
 
   // ---- parameter arena: grouped by backward stage so each stage's gradients are one range
@@ -245,6 +291,18 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
     p.y[m->dec[i].c1] = alloc(sz); p.y[m->dec[i].c2] = alloc(sz);
     p.oh[m->dec[i].c1] = p.oh[m->dec[i].c2] = h; p.ow[m->dec[i].c1] = p.ow[m->dec[i].c2] = w;
   }
+  p.cat.assign(m->nodes.size(), 0);
+  size_t max_gcat = 0, max_dcat = 0;
+  for (size_t i = 0; i < m->nodes.size(); ++i) {
+    const NodeL& nd = m->nodes[i];
+    const int nh = H >> nd.lvl, nw = W >> nd.lvl;
+    const size_t sz = (size_t)N * nh * nw * m->convs[nd.c1].Cout;
+    p.y[nd.c1] = alloc(sz); p.y[nd.c2] = alloc(sz);
+    p.oh[nd.c1] = p.oh[nd.c2] = nh; p.ow[nd.c1] = p.ow[nd.c2] = nw;
+    if (nd.skips.size() > 1) p.cat[i] = alloc((size_t)N * nh * nw * nd.C1);
+    max_gcat = std::max(max_gcat, (size_t)N * nh * nw * nd.C1);
+    max_dcat = std::max(max_dcat, (size_t)N * nh * nw * (nd.C0 + nd.C1));
+  }
   p.oh[m->head] = H; p.ow[m->head] = W;
   if (training) {
     // gradient buffers (same shapes as their activations)
@@ -271,6 +329,17 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       p.g[d.c1] = alloc(sz); p.g[d.c2] = alloc(sz);
       p.dcat[i] = alloc((size_t)N * h * w * (d.C0 + d.C1));
       if (d.C1 > 0) p.gskip[i] = alloc((size_t)N * h * w * d.C1);
+    }
+    if (!m->nodes.empty()) {
+      for (auto& nd : m->nodes) {
+        const size_t sz = (size_t)N * (H >> nd.lvl) * (W >> nd.lvl) * m->convs[nd.c1].Cout;
+        p.g[nd.c1] = alloc(sz); p.g[nd.c2] = alloc(sz);
+      }
+      p.dcat.assign(1, alloc(max_dcat));
+      p.gcat = alloc(max_gcat);
+      const int fc[4] = {256, 128, 64, 64};       // gradient accumulators of f4, f3, f2, f1
+      p.gskip.assign(4, 0);
+      for (int j = 0; j < 4; ++j) p.gskip[j] = alloc((size_t)N * (H >> (4 - j)) * (W >> (4 - j)) * fc[j]);
     }
   }
   p.bytes = off * sizeof(float);
@@ -315,7 +384,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   return launch_conv(a, c.st, cfg);
 }
 
-struct UpSplit { float* gprev; int C0; const float* pmask; const float* pscale; const float* pshift; };
+struct UpSplit { float* gprev; int C0; const float* pmask; const float* pscale; const float* pshift; int accumulate = 0; };
 // dX = dgrad(dY) (+addend) (*mask); with `us`: decoder concat split fused into the epilogue (dx = gskip or nullptr)
 static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int Wo, int Hin, int Win, float* dx,
                             const float* addend, const float* mask, const float* mscale, const float* mshift,
@@ -330,7 +399,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
   if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
-  if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; }
+  if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
   return launch_conv(a, c.st);
 }
 
@@ -477,6 +546,38 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     if (conv_bn(dl.c2, a1, nullptr, h, w)) return 1;
     d = lazy_src(c, dl.c2, h, w);
   }
+  // UnetPlusPlus: dense grid of the same blocks; a node with several skip tensors gets them materialised (activation
+  // applied) into one concat buffer, so every conv still sees two sources
+  auto tensor_src = [&](int id) -> Src {
+    if (id == 0) return f1;
+    if (id < 5) return feats[id - 1];
+    const NodeL& nd = m->nodes[id - 5];
+    return lazy_src(c, nd.c2, H >> nd.lvl, W >> nd.lvl);
+  };
+  for (size_t i = 0; i < m->nodes.size(); ++i) {
+    const NodeL& nd = m->nodes[i];
+    h = H >> nd.lvl; w = W >> nd.lvl;
+    Src up = tensor_src(nd.prev); up.up = 1;
+    if (up.C != nd.C0 || (up.H << 1) != h || (up.W << 1) != w) return fail("internal: UnetPlusPlus node %d input mismatch", (int)i);
+    Src skip; const Src* sp = nullptr;
+    if (nd.skips.size() == 1) { skip = tensor_src(nd.skips[0]); sp = &skip; }
+    else if (nd.skips.size() > 1) {
+      int coff = 0;
+      for (int id : nd.skips) {
+        const Src t = tensor_src(id);
+        if (t.H != h || t.W != w) return fail("internal: UnetPlusPlus node %d skip shape mismatch", (int)i);
+        LCHK(launch_concat_copy(t, (size_t)N * h * w, c.F(p.cat[i]), nd.C1, coff, st));
+        coff += t.C;
+      }
+      if (coff != nd.C1) return fail("internal: UnetPlusPlus node %d skip channels %d != %d", (int)i, coff, nd.C1);
+      skip = mk_src(c.F(p.cat[i]), nd.C1, h, w); sp = &skip;
+    }
+    if (sp && (sp->C != nd.C1)) return fail("internal: UnetPlusPlus node %d skip channel mismatch", (int)i);
+    if (conv_bn(nd.c1, up, sp, h, w)) return 1;
+    Src a1 = lazy_src(c, nd.c1, h, w);
+    if (conv_bn(nd.c2, a1, nullptr, h, w)) return 1;
+    d = lazy_src(c, nd.c2, h, w);
+  }
   (void)h1; (void)w1;
   LCHK(run_conv_fwd(c, m->head, d, nullptr, h, w, logits, false));
   return 0;
@@ -516,11 +617,11 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     }
     // ---------------- head
     const ConvL& hd = m->convs[m->head];
-    const DecL& dl4 = m->dec.back();
-    Src d4 = lazy_src(c, dl4.c2, H, W);
+    const int last_c2 = m->nodes.empty() ? m->dec.back().c2 : m->nodes.back().c2;
+    Src d4 = lazy_src(c, last_c2, H, W);
     LCHK(run_wgrad(c, m->head, d4, nullptr, dlogits, H, W));
     LCHK(launch_colsum(dlogits, (size_t)N * H * W, hd.CoutP, m->grads + hd.bias_off, nullptr, st));
-    LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[dl4.c2]), nullptr, d4.ptr, d4.scale, d4.shift));
+    LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[last_c2]), nullptr, d4.ptr, d4.scale, d4.shift));
     // ---------------- decoder blocks, last to first
     int h = H, w = W;
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
@@ -542,7 +643,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       if (c1v.wud_off && p.wino_ok((size_t)dl.c1) && !(h & 1) && !(w & 1)) {
         // Winograd dgrad writes the 2x2-pooled, ReLU-masked gradient of up(prev) and the skip gradient directly:
         // the full-resolution dcat buffer and the upsplit pass never exist
-        UpSplit us{gprev, dl.C0, prev.ptr, prev.scale, prev.shift};
+        UpSplit us{gprev, dl.C0, prev.ptr, prev.scale, prev.shift, 0};
         LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, nullptr, nullptr, nullptr,
                        nullptr, &us));
       } else {
@@ -551,6 +652,64 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
                             dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, st));
       }
       h /= 2; w /= 2;
+    }
+    // ---------------- UnetPlusPlus nodes, last to first.  A tensor feeds several nodes: the first contribution to its
+    // gradient buffer (in this order) writes, the others accumulate; ReLU masks are 0/1 factors, so masking each
+    // contribution separately equals masking the sum.
+    if (!m->nodes.empty()) {
+      std::vector<char> ginit(5 + m->nodes.size(), 0);
+      ginit[5 + m->nodes.size() - 1] = 1;                    // the head dgrad wrote the last node's gradient
+      auto tensor_src = [&](int id) -> Src {
+        if (id == 0) return f1;
+        if (id < 5) return feat_src(id - 1);
+        const NodeL& nd = m->nodes[id - 5];
+        return lazy_src(c, nd.c2, H >> nd.lvl, W >> nd.lvl);
+      };
+      auto tensor_grad = [&](int id) -> float* {             // f1..f4 -> gskip[3..0], f5 -> gx of the last encoder block
+        if (id < 4) return c.F(p.gskip[3 - id]);
+        if (id == 4) return c.F(p.gx[first_blk[3] + m->stages[3].size() - 1]);
+        return c.F(p.g[m->nodes[id - 5].c2]);
+      };
+      for (int i = (int)m->nodes.size() - 1; i >= 0; --i) {
+        const NodeL& nd = m->nodes[i];
+        const int nh = H >> nd.lvl, nw = W >> nd.lvl;
+        const size_t npix = (size_t)N * nh * nw;
+        if (!ginit[5 + i]) return fail("internal: UnetPlusPlus node %d has no consumer", i);
+        LCHK(run_bn_bwd(c, nd.c2, c.F(p.g[nd.c2]), c.F(p.g[nd.c2]), npix));
+        Src a1 = lazy_src(c, nd.c1, nh, nw);
+        LCHK(run_wgrad(c, nd.c2, a1, nullptr, c.F(p.g[nd.c2]), nh, nw));
+        LCHK(run_dgrad(c, nd.c2, c.F(p.g[nd.c2]), nh, nw, nh, nw, c.F(p.g[nd.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
+        LCHK(run_bn_bwd(c, nd.c1, c.F(p.g[nd.c1]), c.F(p.g[nd.c1]), npix));
+        Src prev = tensor_src(nd.prev); prev.up = 1;
+        Src skip; const Src* sp = nullptr;
+        if (nd.skips.size() == 1) { skip = tensor_src(nd.skips[0]); sp = &skip; }
+        else if (nd.skips.size() > 1) { skip = mk_src(c.F(p.cat[i]), nd.C1, nh, nw); sp = &skip; }
+        LCHK(run_wgrad(c, nd.c1, prev, sp, c.F(p.g[nd.c1]), nh, nw));
+        float* gprev = tensor_grad(nd.prev);
+        const int acc_prev = ginit[nd.prev]; ginit[nd.prev] = 1;
+        const ConvL& c1v = m->convs[nd.c1];
+        const float* gcat; int gcc, gco;                      // where the skip part of the gradient lands
+        if (c1v.wud_off && p.wino_ok((size_t)nd.c1) && !(nh & 1) && !(nw & 1)) {
+          UpSplit us{gprev, nd.C0, prev.ptr, prev.scale, prev.shift, acc_prev};
+          LCHK(run_dgrad(c, nd.c1, c.F(p.g[nd.c1]), nh, nw, nh, nw, nd.C1 > 0 ? c.F(p.gcat) : nullptr, nullptr, nullptr, nullptr,
+                         nullptr, &us));
+          gcat = c.F(p.gcat); gcc = nd.C1; gco = 0;
+        } else {
+          LCHK(run_dgrad(c, nd.c1, c.F(p.g[nd.c1]), nh, nw, nh, nw, c.F(p.dcat[0]), nullptr, nullptr, nullptr, nullptr));
+          LCHK(launch_upsplit(c.F(p.dcat[0]), N, nh, nw, nd.C0, nd.C1, gprev, prev.ptr, prev.scale, prev.shift, nullptr, st, acc_prev));
+          gcat = c.F(p.dcat[0]); gcc = nd.C0 + nd.C1; gco = nd.C0;
+        }
+        int coff = 0;
+        for (int id : nd.skips) {
+          const Src t = tensor_src(id);
+          const bool lazy_mask = id >= 5;                     // node outputs: mask by their own ReLU; encoder features: the encoder masks
+          LCHK(launch_split_accum(gcat, gcc, gco + coff, t.C, npix, tensor_grad(id), lazy_mask ? t.ptr : nullptr,
+                                  lazy_mask ? t.scale : nullptr, lazy_mask ? t.shift : nullptr, ginit[id], st));
+          ginit[id] = 1;
+          coff += t.C;
+        }
+      }
+      for (int id = 0; id < 5; ++id) if (!ginit[id]) return fail("internal: UnetPlusPlus feature %d received no gradient", id);
     }
   }
   // ---------------- encoder stages: backward stage k handles encoder stage s = 4 - k

@@ -62,6 +62,7 @@ class Unet(nn.Module):
     """MI355X-native U-Net (ResNet-18/34 encoder, smp UnetDecoder, 3x3 segmentation head)."""
 
     SUPPORTED_ENCODERS = tuple(L.ENC)
+    _ARCH = "Unet"
 
     def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5,
                  encoder_weights: Optional[str] = None, decoder_use_batchnorm: bool = True,
@@ -94,7 +95,7 @@ class Unet(nn.Module):
         self.decoder_channels = decoder_channels
         lib = L.lib()
         desc = L.uwm_unet_desc(L.ENC[encoder_name], self.in_channels, self.classes,
-                               (C.c_int * 5)(*decoder_channels), 1e-5, 0.1)
+                               (C.c_int * 5)(*decoder_channels), 1e-5, 0.1, L.ARCH[self._ARCH])
         h = C.c_void_p()
         L.check(lib.uwm_create(C.byref(desc), C.byref(h)), ValueError)
         self._h = h
@@ -314,8 +315,15 @@ class Unet(nn.Module):
 _PADDED_PTRS: set = set()
 
 
+class UnetPlusPlus(Unet):
+    """MI355X-native UNet++ (smp.UnetPlusPlus: ResNet-18/34 encoder, dense x_{depth}_{layer} decoder grid) — the
+    reference's default architecture (MODEL.NAME, /root/reference/src/configs/config.py:15).  Same constructor
+    surface, arenas, kernels and training path as `Unet`; state_dict keys `decoder.blocks.x_0_0.conv1.0.weight` ..."""
+    _ARCH = "UnetPlusPlus"
+
+
 # ---------------------------------------------------------------------------- factory (reference L3 glue)
-SUPPORTED_MODELS = {"Unet": Unet}
+SUPPORTED_MODELS = {"Unet": Unet, "UnetPlusPlus": UnetPlusPlus}
 
 
 def create_model(model_name: str, encoder_name: str = "resnet34", encoder_weights: Optional[str] = None,
