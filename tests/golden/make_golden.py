@@ -20,8 +20,8 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(4)
 
 
-def unet_case(name, enc, n, h, w, seed, loss="dice"):
-    model = O.build(enc, seed=seed)
+def unet_case(name, enc, n, h, w, seed, loss="dice", arch="Unet"):
+    model = O.build(enc, seed=seed, arch=arch)
     model.train()
     x, t = O.synthetic_batch(n, h, w, seed=seed)
     crit = O.DiceLoss(smooth=1e-5) if loss == "dice" else O.CombinedLoss(
@@ -46,7 +46,7 @@ def unet_case(name, enc, n, h, w, seed, loss="dice"):
     o = out.detach()
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
-        encoder=enc, n=n, h=h, w=w, seed=seed, loss=loss,
+        encoder=enc, arch=arch, n=n, h=h, w=w, seed=seed, loss=loss,
         logits_crop=o[:, :, :32, :32].numpy(), logits_sum=float(o.double().sum()),
         logits_abs_sum=float(o.double().abs().sum()), loss_total=float(l), loss_dice=float(dice), loss_bce=float(bce),
         param_names=np.array(names), grad_norm=np.array(gnorm), grad_sample=np.stack(gsample),
@@ -80,6 +80,7 @@ if __name__ == "__main__":
     unet_case("unet_r18_256", "resnet18", 1, 256, 256, 42, "dice")      # BASELINE config 1
     unet_case("unet_r18_64_combo", "resnet18", 2, 64, 64, 7, "combo")
     unet_case("unet_r34_64", "resnet34", 1, 64, 64, 3, "dice")
+    unet_case("unetpp_r18_64_combo", "resnet18", 2, 64, 64, 11, "combo", arch="UnetPlusPlus")
     kernel_cases()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

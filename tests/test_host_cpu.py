@@ -69,7 +69,9 @@ def test_constructor_rejects_unsupported(U):
         with pytest.raises(ValueError):
             U.Unet(**kw)
     with pytest.raises(ValueError, match="Unsupported model"):
-        U.create_model("UnetPlusPlus")
+        U.create_model("DeepLabV3Plus")
+    with pytest.raises(ValueError):
+        U.UnetPlusPlus(encoder_name="efficientnet-b4")
 
 
 def test_config_factories(U):
@@ -79,6 +81,14 @@ def test_config_factories(U):
                       ENCODER_DEPTH=5, DECODER_CHANNELS=[256, 128, 64, 32, 16]),
              LOSS=NS(NAME="DiceLoss", MODE="binary", SMOOTH=1e-5, BCE_WEIGHT=0.5, DICE_WEIGHT=0.5))
     assert isinstance(U.create_model_from_config(cfg), U.Unet)
+    cfg.MODEL.NAME = "UnetPlusPlus"                      # the reference's default MODEL.NAME
+    mpp = U.create_model_from_config(cfg)
+    assert isinstance(mpp, U.UnetPlusPlus)
+    from oracle import unet_oracle as O
+    ref = O.build("resnet18", arch="UnetPlusPlus")
+    assert list(mpp.state_dict().keys()) == list(ref.state_dict().keys())
+    assert all(mpp.state_dict()[k].shape == v.shape for k, v in ref.state_dict().items())
+    mpp.load_state_dict(ref.state_dict())
     assert isinstance(U.get_loss_function(cfg), U.DiceLoss)
     cfg.LOSS.NAME = "CombinedLoss"
     assert isinstance(U.get_loss_function(cfg), U.CombinedLoss)

@@ -27,6 +27,27 @@ def test_parameter_counts_and_state_dict_keys():
     assert not any(k.startswith("encoder.fc") for k in keys)
 
 
+def test_unetplusplus_structure():
+    """smp.UnetPlusPlus decoder restatement: parameter counts of the public smp models, ModuleDict key order,
+    block shapes of the dense grid (the reference's default MODEL.NAME)."""
+    m34, m18 = O.build("resnet34", arch="UnetPlusPlus"), O.build("resnet18", arch="UnetPlusPlus")
+    assert sum(p.numel() for p in m34.parameters()) == 26_078_609
+    assert sum(p.numel() for p in m18.parameters()) == 15_970_449
+    sd = m34.state_dict()
+    blocks = []
+    for k in sd:
+        if k.startswith("decoder.blocks.") and k.endswith(".conv1.0.weight"):
+            blocks.append(k.split(".")[2])
+    assert blocks == ["x_0_0", "x_0_1", "x_1_1", "x_0_2", "x_1_2", "x_2_2", "x_0_3", "x_1_3", "x_2_3", "x_3_3", "x_0_4"]
+    shapes = {b: tuple(sd[f"decoder.blocks.{b}.conv1.0.weight"].shape[:2]) for b in blocks}
+    assert shapes == {"x_0_0": (256, 768), "x_0_1": (128, 512), "x_1_1": (128, 384), "x_0_2": (64, 320), "x_1_2": (64, 256),
+                      "x_2_2": (64, 192), "x_0_3": (32, 320), "x_1_3": (64, 256), "x_2_3": (64, 192), "x_3_3": (64, 128),
+                      "x_0_4": (16, 32)}
+    assert O.conv_flops("resnet34", 512, 512, arch="UnetPlusPlus") == (147_069_075_456, 439_974_100_992)
+    x = torch.randn(1, 3, 64, 96)
+    assert m18(x).shape == (1, 1, 64, 96)
+
+
 def test_conv_flops_match_survey():
     assert O.conv_flops("resnet34", 512, 512) == (62_511_906_816, 186_302_595_072)
     assert O.conv_flops("resnet18", 256, 256) == (10_796_138_496, 32_080_134_144)
@@ -72,11 +93,11 @@ def test_metrics_closed_forms():
     assert O.predict_mask(lg, 0.5, apply_sigmoid=True).flatten().tolist() == [255, 255, 0, 255]
 
 
-@pytest.mark.parametrize("name", ["unet_r18_256", "unet_r18_64_combo", "unet_r34_64"])
+@pytest.mark.parametrize("name", ["unet_r18_256", "unet_r18_64_combo", "unet_r34_64", "unetpp_r18_64_combo"])
 def test_oracle_reproduces_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     enc, n, h, w, seed, loss = str(g["encoder"]), int(g["n"]), int(g["h"]), int(g["w"]), int(g["seed"]), str(g["loss"])
-    model = O.build(enc, seed=seed)
+    model = O.build(enc, seed=seed, arch=str(g["arch"]) if "arch" in g.files else "Unet")
     model.train()
     x, t = O.synthetic_batch(n, h, w, seed=seed)
     out = model(x)

@@ -158,7 +158,7 @@ static int build_model(uwm_model* m) {
       prev = out;
     }
   } else if (d.arch == UWM_ARCH_UNETPLUSPLUS) {
-    // smp UnetPlusPlusDecoder (SURVEY.md App. A / oracle/unet_oracle.py OracleUnetPlusPlus): blocks x_{depth}_{layer}
+    // smp UnetPlusPlusDecoder (src/configs/config.py:15 default MODEL.NAME): blocks x_{depth}_{layer}
     const int in_ch[5] = {encc[0], d.decoder_channels[0], d.decoder_channels[1], d.decoder_channels[2], d.decoder_channels[3]};
     const int skip_ch[5] = {encc[1], encc[2], encc[3], encc[4], 0};
     int blk_c1[5][5], blk_c2[5][5], blk_in[5][5], blk_skip[5][5];
