@@ -122,6 +122,15 @@ int  uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, fl
                    float eps, float weight_decay, long long step, float grad_scale, float max_norm, void* scratch,
                    uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
+/* Input pipeline on the device (src/utils/dataset.py:298-395 get_*_transform tails): uint8 HWC images [N][H][W][C] ->
+ * Normalize(mean, std) of x/255 as NCHW fp32 (what uwm_forward takes); uint8 masks [N][H][W] -> (m > threshold) as
+ * uint8 {0,1} (what uwm_loss takes).  flags (device int[N] or NULL): bit0 HorizontalFlip, bit1 VerticalFlip, bits 2-3
+ * k of RandomRotate90 (counter-clockwise, needs H == W), applied flips first, then the rotation — the same flags on
+ * image and mask keep them aligned.  mean/std are host pointers (C values). */
+int  uwm_preprocess_u8(const uint8_t* images, int N, int H, int W, int C, const float* mean, const float* std,
+                       const int* flags, float* out_nchw, uwm_stream stream);
+int  uwm_preprocess_mask_u8(const uint8_t* masks, int N, int H, int W, int threshold, const int* flags, uint8_t* out,
+                            uwm_stream stream);
 /* 3x3/stride-1 convolutions (forward and dgrad) run as Winograd F(2x2,3x3) on the fp32 MFMA path by default
  * (2.25x fewer multiplies, results within a few fp32 ulps of the direct form); 0 selects the direct kernels
  * everywhere; 2 (tests) prefers the 512-thread Winograd variant wherever its shape rules allow, whatever the

@@ -455,3 +455,33 @@ def test_adam_with_global_norm_clipping(cuda):
                                   C.c_void_p(scr.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert abs(float(scr[0]) ** 0.5 - float(gr.norm())) < 1e-3 * float(gr.norm())
     assert (p.cpu() - pr.detach()).abs().max() < 2e-6
+
+
+def test_device_input_pipeline_matches_reference_transform(cuda):
+    """uint8 HWC -> Normalize -> NCHW fp32 with HorizontalFlip / VerticalFlip / RandomRotate90 as index arithmetic
+    (dataset.py get_*_transform tails): bit-exact geometry, fp32-rounding on the normalisation."""
+    import unet_watermark_amd as U
+    g = torch.Generator().manual_seed(3)
+    n, s = 6, 32
+    img = torch.randint(0, 256, (n, s, s, 3), generator=g, dtype=torch.uint8)
+    msk = (torch.randint(0, 2, (n, s, s), generator=g) * 255).to(torch.uint8)
+    flags = torch.tensor([U.aug_flags(), U.aug_flags(hflip=True), U.aug_flags(vflip=True), U.aug_flags(rot90=1),
+                          U.aug_flags(hflip=True, vflip=True, rot90=3), U.aug_flags(vflip=True, rot90=2)], dtype=torch.int32)
+    mean = torch.tensor(U.data.IMAGENET_MEAN).view(3, 1, 1); std = torch.tensor(U.data.IMAGENET_STD).view(3, 1, 1)
+    x, m = U.device_preprocess(img.to(cuda), msk.to(cuda), flags)
+    for i in range(n):
+        f = int(flags[i])
+        a, b = img[i].permute(2, 0, 1), msk[i]
+        if f & 1: a, b = a.flip(-1), b.flip(-1)
+        if f & 2: a, b = a.flip(-2), b.flip(-2)
+        k = (f >> 2) & 3
+        a, b = torch.rot90(a, k, (-2, -1)), torch.rot90(b, k, (-2, -1))
+        ref = (a.float() / 255.0 - mean) / std
+        assert (x[i].cpu() - ref).abs().max() < 1e-5, i
+        assert torch.equal(m[i].cpu(), (b > 127).to(torch.uint8)), i
+    # non-square images without rotation; no flags
+    img2 = torch.randint(0, 256, (2, 16, 24, 3), generator=g, dtype=torch.uint8)
+    x2 = U.device_preprocess(img2.to(cuda))
+    assert (x2.cpu() - (img2.permute(0, 3, 1, 2).float() / 255.0 - mean) / std).abs().max() < 1e-5
+    with pytest.raises(ValueError):
+        U.device_preprocess(img2.to(cuda), flags=torch.tensor([4, 0], dtype=torch.int32))

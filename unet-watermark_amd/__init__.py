@@ -10,3 +10,5 @@ from .losses import DiceLoss, BCEWithLogitsLoss, CombinedLoss, get_loss_function
 from .metrics import get_metrics, get_stats, micro_scores, logits_metrics, threshold_mask, resize_threshold  # noqa: F401
 
 __version__ = "0.1.0"
+
+from .data import device_preprocess, aug_flags, random_aug_flags  # noqa: F401,E402

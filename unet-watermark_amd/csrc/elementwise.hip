@@ -309,6 +309,59 @@ hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ input pipeline on the device
+// uint8 HWC image (and its uint8 mask) -> the tensors the train step takes: Normalize(mean, std) of x/255 in NCHW
+// fp32, mask > thr as uint8 {0,1}; the exact geometric augmentations of dataset.py's transforms (HorizontalFlip,
+// VerticalFlip, RandomRotate90) are index arithmetic in the same pass.  flags[n]: bit0 hflip, bit1 vflip,
+// bits 2-3 = k of rot90 (counter-clockwise, numpy/torch convention; needs H == W), applied in albumentations'
+// pipeline order: flips first, then the rotation.
+struct PreArgs { float mul[4], add[4]; };
+__device__ __forceinline__ void aug_src(int flags, int H, int W, int y, int x, int& sy, int& sx) {
+  // output (y, x) of rot90^k(flip(img)) -> coordinates in the flipped image, then undo the flips
+  const int k = (flags >> 2) & 3;
+  int fy = y, fx = x;
+  if (k == 1) { fy = x; fx = W - 1 - y; }            // torch.rot90(a, 1)[y][x] = a[x][W-1-y]
+  else if (k == 2) { fy = H - 1 - y; fx = W - 1 - x; }
+  else if (k == 3) { fy = H - 1 - x; fx = y; }
+  if (flags & 1) fx = W - 1 - fx;
+  if (flags & 2) fy = H - 1 - fy;
+  sy = fy; sx = fx;
+}
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ img, int H, int W, int C, PreArgs pa,
+                                     const int* __restrict__ flags, float* __restrict__ out, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); size_t r = i / W;
+    const int y = (int)(r % H); const int n = (int)(r / H);
+    int sy, sx; aug_src(flags ? flags[n] : 0, H, W, y, x, sy, sx);
+    const uint8_t* p = img + (((size_t)n * H + sy) * W + sx) * C;
+    for (int c = 0; c < C; ++c) out[(((size_t)n * C + c) * H + y) * W + x] = (float)p[c] * pa.mul[c] + pa.add[c];
+  }
+}
+__global__ void preprocess_mask_kernel(const uint8_t* __restrict__ m, int H, int W, int thr, const int* __restrict__ flags,
+                                       uint8_t* __restrict__ out, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); size_t r = i / W;
+    const int y = (int)(r % H); const int n = (int)(r / H);
+    int sy, sx; aug_src(flags ? flags[n] : 0, H, W, y, x, sy, sx);
+    out[i] = m[((size_t)n * H + sy) * W + sx] > thr ? 1 : 0;
+  }
+}
+hipError_t launch_preprocess_u8(const uint8_t* img, int N, int H, int W, int C, const float* mean, const float* std,
+                                const int* flags, float* out, hipStream_t st) {
+  if (C < 1 || C > 4) return hipErrorInvalidValue;
+  PreArgs pa;
+  for (int c = 0; c < 4; ++c) { pa.mul[c] = 0.f; pa.add[c] = 0.f; }
+  for (int c = 0; c < C; ++c) { pa.mul[c] = 1.f / (255.f * std[c]); pa.add[c] = -mean[c] / std[c]; }
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, img, H, W, C, pa, flags, out, total);
+  return hipGetLastError();
+}
+hipError_t launch_preprocess_mask(const uint8_t* m, int N, int H, int W, int thr, const int* flags, uint8_t* out, hipStream_t st) {
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(preprocess_mask_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, m, H, W, thr, flags, out, total);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ UNet++ dense skip plumbing
 // dst[pix][dst_off + c] = act(src[pix][c])   (act = lazy BatchNorm scale/shift + ReLU of the producer, or identity)
 __global__ void concat_copy_kernel(const float* __restrict__ src, const float* __restrict__ scale,

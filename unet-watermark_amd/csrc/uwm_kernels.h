@@ -147,6 +147,9 @@ hipError_t launch_sumsq(const float* g, size_t n, double* out, hipStream_t st);
 hipError_t launch_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float thr,
                                    int apply_sigmoid, uint8_t* out, float* out_f, hipStream_t st);
 hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st);
+hipError_t launch_preprocess_u8(const uint8_t* img, int N, int H, int W, int C, const float* mean, const float* std,
+                                const int* flags, float* out, hipStream_t st);
+hipError_t launch_preprocess_mask(const uint8_t* m, int N, int H, int W, int thr, const int* flags, uint8_t* out, hipStream_t st);
 
 // loss / metrics (loss.hip)
 hipError_t launch_loss(const float* logits, int ld, const void* target, int tdtype, size_t npix_total,

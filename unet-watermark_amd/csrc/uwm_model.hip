@@ -900,6 +900,19 @@ int uwm_resize_threshold(const float* logits, int ld, int N, int h, int w, int H
   LCHK(launch_resize_threshold(logits, ld, N, h, w, H, W, threshold, apply_sigmoid, mask, resized, (hipStream_t)stream));
   return 0;
 }
+int uwm_preprocess_u8(const uint8_t* images, int N, int H, int W, int C, const float* mean, const float* std, const int* flags,
+                      float* out_nchw, uwm_stream stream) {
+  if (!images || !mean || !std || !out_nchw || N < 1 || H < 1 || W < 1 || C < 1 || C > 4) return fail("uwm_preprocess_u8: bad argument");
+  for (int c = 0; c < C; ++c) if (!(std[c] > 0.f)) return fail("uwm_preprocess_u8: std[%d] must be positive", c);
+  LCHK(launch_preprocess_u8(images, N, H, W, C, mean, std, flags, out_nchw, (hipStream_t)stream));
+  return 0;
+}
+int uwm_preprocess_mask_u8(const uint8_t* masks, int N, int H, int W, int threshold, const int* flags, uint8_t* out,
+                           uwm_stream stream) {
+  if (!masks || !out || N < 1 || H < 1 || W < 1) return fail("uwm_preprocess_mask_u8: bad argument");
+  LCHK(launch_preprocess_mask(masks, N, H, W, threshold, flags, out, (hipStream_t)stream));
+  return 0;
+}
 int uwm_scale(float* p, long long n, float s, uwm_stream stream) {
   if (!p || n < 1) return fail("uwm_scale: bad argument");
   LCHK(launch_scale(p, (size_t)n, s, (hipStream_t)stream));

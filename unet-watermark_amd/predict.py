@@ -38,10 +38,8 @@ class WatermarkPredictor:
 
     # --- input contract of dataset.get_val_transform: Resize -> Normalize(ImageNet) -> NCHW fp32
     def preprocess(self, images_u8_nhwc: torch.Tensor) -> torch.Tensor:
-        x = images_u8_nhwc.to(self.device).permute(0, 3, 1, 2).float().div_(255.0)
-        mean = torch.tensor(IMAGENET_MEAN, device=self.device).view(1, 3, 1, 1)
-        std = torch.tensor(IMAGENET_STD, device=self.device).view(1, 3, 1, 1)
-        return ((x - mean) / std).contiguous()
+        from .data import device_preprocess
+        return device_preprocess(images_u8_nhwc.to(self.device, non_blocking=True))      # one kernel: uint8 HWC -> normalised NCHW fp32
 
     @torch.no_grad()
     def logits(self, x: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
