@@ -37,7 +37,7 @@ extern "C" {
 typedef struct uwm_model* uwm_handle;
 typedef void* uwm_stream;              /* hipStream_t */
 
-enum { UWM_ENC_RESNET18 = 18, UWM_ENC_RESNET34 = 34 };
+enum { UWM_ENC_RESNET18 = 18, UWM_ENC_RESNET34 = 34, UWM_ENC_RESNET50 = 50 };   /* 50: Bottleneck blocks (unet_watermark_large.yaml) */
 enum { UWM_ARCH_UNET = 0, UWM_ARCH_UNETPLUSPLUS = 1 };   /* smp.Unet | smp.UnetPlusPlus (the reference's default MODEL.NAME, src/configs/config.py:15) */
 enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* target dtypes */
 enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
@@ -46,7 +46,7 @@ enum { UWM_ARENA_PARAM = 0, UWM_ARENA_BUFFER = 1 };
 
 /* mirrors smp.Unet(encoder_name, encoder_depth=5, decoder_channels, in_channels, classes) */
 typedef struct {
-  int encoder;                 /* UWM_ENC_RESNET18 | UWM_ENC_RESNET34 */
+  int encoder;                 /* UWM_ENC_RESNET18 | UWM_ENC_RESNET34 | UWM_ENC_RESNET50 */
   int in_channels;             /* 1..4 */
   int classes;                 /* >= 1 */
   int decoder_channels[5];     /* e.g. 256,128,64,32,16 ; each a multiple of 4 */

@@ -33,8 +33,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# resnet block counts: torchvision.models.resnet{18,34} (BasicBlock)
-_RESNET_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+# resnet block counts: torchvision.models.resnet{18,34} (BasicBlock), resnet50 (Bottleneck, expansion 4)
+_RESNET_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3)}
+_RESNET_EXPANSION = {"resnet18": 1, "resnet34": 1, "resnet50": 4}
 _RESNET_WIDTHS = (64, 128, 256, 512)
 
 
@@ -60,6 +61,34 @@ class BasicBlock(nn.Module):
         return self.relu(o + idn)
 
 
+class Bottleneck(nn.Module):
+    """torchvision Bottleneck (v1.5: the stride sits on the 3x3): 1x1-bn-relu, 3x3(stride)-bn-relu, 1x1(x4)-bn
+    (+downsample) -add-relu.  The encoder of the reference's large config
+    (/root/reference/src/configs/unet_watermark_large.yaml:7-10, ENCODER_NAME resnet50)."""
+
+    def __init__(self, cin: int, planes: int, stride: int):
+        super().__init__()
+        cout = planes * 4
+        self.conv1 = nn.Conv2d(cin, planes, 1, 1, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, cout, 1, 1, 0, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=False)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride, 0, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idn = x if self.downsample is None else self.downsample(x)
+        o = self.relu(self.bn1(self.conv1(x)))
+        o = self.relu(self.bn2(self.conv2(o)))
+        o = self.bn3(self.conv3(o))
+        return self.relu(o + idn)
+
+
 class ResNetEncoder(nn.Module):
     """smp ResNetEncoder (fc/avgpool deleted); features at strides 1,2,4,8,16,32."""
 
@@ -71,13 +100,15 @@ class ResNetEncoder(nn.Module):
         self.relu = nn.ReLU(inplace=False)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         cin = 64
+        exp = _RESNET_EXPANSION[name]
         for li, (w, nb) in enumerate(zip(_RESNET_WIDTHS, blocks), start=1):
             layer = []
             for b in range(nb):
-                layer.append(BasicBlock(cin, w, 2 if (b == 0 and li > 1) else 1))
-                cin = w
+                stride = 2 if (b == 0 and li > 1) else 1
+                layer.append(BasicBlock(cin, w, stride) if exp == 1 else Bottleneck(cin, w, stride))
+                cin = w * exp
             setattr(self, f"layer{li}", nn.Sequential(*layer))
-        self.out_channels = (in_channels, 64, 64, 128, 256, 512)
+        self.out_channels = (in_channels, 64, 64 * exp, 128 * exp, 256 * exp, 512 * exp)
         # torchvision ResNet init (encoder_weights=None)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -355,16 +386,23 @@ def conv_flops(encoder_name="resnet34", h=512, w=512, decoder_channels=(256, 128
         macs.append((cin * cout * k * k * ho * wo, dgrad))
     conv(in_channels, 64, 7, h // 2, w // 2, dgrad=False)
     cin, hh, ww = 64, h // 4, w // 4
+    exp = _RESNET_EXPANSION[encoder_name]
     for li, (wd, nb) in enumerate(zip(_RESNET_WIDTHS, _RESNET_BLOCKS[encoder_name]), start=1):
         for b in range(nb):
             s = 2 if (b == 0 and li > 1) else 1
-            hh, ww = hh // s, ww // s
-            conv(cin, wd, 3, hh, ww)
-            conv(wd, wd, 3, hh, ww)
-            if s != 1 or cin != wd:
+            if exp == 1:
+                hh, ww = hh // s, ww // s
+                conv(cin, wd, 3, hh, ww)
+                conv(wd, wd, 3, hh, ww)
+            else:
                 conv(cin, wd, 1, hh, ww)
-            cin = wd
-    enc = [512, 256, 128, 64, 64]
+                hh, ww = hh // s, ww // s
+                conv(wd, wd, 3, hh, ww)
+                conv(wd, wd * exp, 1, hh, ww)
+            if s != 1 or cin != wd * exp:
+                conv(cin, wd * exp, 1, hh, ww)
+            cin = wd * exp
+    enc = [512 * exp, 256 * exp, 128 * exp, 64 * exp, 64]
     in_ch = [enc[0]] + list(decoder_channels[:-1])
     skip = enc[1:] + [0]
     if arch == "Unet":

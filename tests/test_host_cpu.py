@@ -89,6 +89,11 @@ def test_config_factories(U):
     assert list(mpp.state_dict().keys()) == list(ref.state_dict().keys())
     assert all(mpp.state_dict()[k].shape == v.shape for k, v in ref.state_dict().items())
     mpp.load_state_dict(ref.state_dict())
+    cfg.MODEL.NAME, cfg.MODEL.ENCODER_NAME = "Unet", "resnet50"       # unet_watermark_large.yaml's encoder
+    m50 = U.create_model_from_config(cfg)
+    r50 = O.build("resnet50")
+    assert list(m50.state_dict().keys()) == list(r50.state_dict().keys())
+    assert all(m50.state_dict()[k].shape == v.shape for k, v in r50.state_dict().items())
     assert isinstance(U.get_loss_function(cfg), U.DiceLoss)
     cfg.LOSS.NAME = "CombinedLoss"
     assert isinstance(U.get_loss_function(cfg), U.CombinedLoss)

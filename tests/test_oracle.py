@@ -48,6 +48,19 @@ def test_unetplusplus_structure():
     assert m18(x).shape == (1, 1, 64, 96)
 
 
+def test_resnet50_structure():
+    """Bottleneck encoder (unet_watermark_large.yaml): the public smp parameter counts for classes=1."""
+    m = O.build("resnet50")
+    assert sum(p.numel() for p in m.parameters()) == 32_521_105
+    assert sum(p.numel() for p in O.build("resnet50", arch="UnetPlusPlus").parameters()) == 48_985_745
+    sd = m.state_dict()
+    assert sd["encoder.layer1.0.conv1.weight"].shape == (64, 64, 1, 1) and sd["encoder.layer1.0.conv3.weight"].shape == (256, 64, 1, 1)
+    assert sd["encoder.layer1.0.downsample.0.weight"].shape == (256, 64, 1, 1)
+    assert sd["encoder.layer2.0.conv2.weight"].shape == (128, 128, 3, 3)
+    assert sd["decoder.blocks.0.conv1.0.weight"].shape == (256, 3072, 3, 3)
+    assert m.encoder.out_channels == (3, 64, 256, 512, 1024, 2048)
+
+
 def test_conv_flops_match_survey():
     assert O.conv_flops("resnet34", 512, 512) == (62_511_906_816, 186_302_595_072)
     assert O.conv_flops("resnet18", 256, 256) == (10_796_138_496, 32_080_134_144)

@@ -35,7 +35,7 @@ class uwm_src(C.Structure):
 
 KIND_CONV_W, KIND_BIAS, KIND_BN_GAMMA, KIND_BN_BETA, KIND_BN_MEAN, KIND_BN_VAR = range(6)
 ARENA_PARAM, ARENA_BUFFER = 0, 1
-ENC = {"resnet18": 18, "resnet34": 34}
+ENC = {"resnet18": 18, "resnet34": 34, "resnet50": 50}
 ARCH = {"Unet": 0, "UnetPlusPlus": 1}
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 

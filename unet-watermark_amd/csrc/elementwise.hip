@@ -208,10 +208,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             double* dgamma, double* dbeta, size_t npix, int C) {
   __shared__ float red[256 * 8];
-  const int tc = C / 4;                       // threads along channels (<= 256)
+  const int CW = C > 1024 ? 1024 : C;         // channels per blockIdx.y slice (wide layers: resnet50's 2048)
+  const int c0 = blockIdx.y * CW;
+  const int tc = CW / 4;                      // threads along channels (<= 256)
   const int tr = 256 / tc;                    // pixel rows per pass
   const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
-  const int c = cx * 4;
+  const int c = c0 + cx * 4;
   f4 sg = {0, 0, 0, 0}, sgy = {0, 0, 0, 0};
   if (rx < tr) {
     const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c);
@@ -228,16 +230,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int q = t / 8, e = t % 8;
     double s = 0.0;
     for (int k = 0; k < tr; ++k) s += (double)red[(k * tc + q) * 8 + e];
-    if (e < 4) atomicAdd(dbeta + q * 4 + e, s); else atomicAdd(dgamma + q * 4 + (e - 4), s);
+    if (e < 4) atomicAdd(dbeta + c0 + q * 4 + e, s); else atomicAdd(dgamma + c0 + q * 4 + (e - 4), s);
   }
 }
 hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mean, const float* rstd, double* dgamma,
                                 double* dbeta, size_t npix, int C, hipStream_t st) {
-  if (C > 1024 || (C & 3) || (256 % (C / 4 > 256 ? 256 : C / 4))) return hipErrorInvalidValue;
-  if (C / 4 > 256) return hipErrorInvalidValue;
-  const int tr = 256 / (C / 4);
+  const int CW = C > 1024 ? 1024 : C;
+  if ((C & 3) || (C % CW) || (256 % (CW / 4))) return hipErrorInvalidValue;
+  const int tr = 256 / (CW / 4);
   unsigned nb = nblocks(npix, tr * 8);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g, y, mean, rstd, dgamma, dbeta, npix, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CW), dim3(256), 0, st, g, y, mean, rstd, dgamma, dbeta, npix, C);
   return hipGetLastError();
 }
 

@@ -47,7 +47,8 @@ struct ConvL {
   bool wino() const { return k == 3 && stride == 1 && pad == 1 && (CinP & 7) == 0; }
   bool wino_d() const { return dgrad && k == 3 && stride == 1 && pad == 1 && (CoutP & 7) == 0; }
 };
-struct BlockL { int c1, c2, cd; };
+// encoder residual block.  BasicBlock: c1 3x3(stride) -> c2 3x3, c3 = -1.  Bottleneck: c1 1x1 -> c2 3x3(stride) -> c3 1x1(x4).
+struct BlockL { int c1, c2, cd, c3 = -1, stride = 1, Cin = 0, Cout = 0; int last() const { return c3 >= 0 ? c3 : c2; } };
 struct DecL { int c1, c2, C0, C1; };
 // UnetPlusPlus decoder block.  Tensor ids: 0..4 = encoder features f1..f5 (f1 = stem, f5 = deepest), 5 + i = output
 // of node i.  lvl = log2 of the down-scale of the node's OUTPUT (f1: 1 ... f5: 5, final node: 0).
@@ -74,6 +75,7 @@ struct uwm_model {
   std::vector<std::vector<BlockL>> stages;   // 4 encoder stages
   std::vector<DecL> dec;
   std::vector<NodeL> nodes;          // UnetPlusPlus (arch 1) decoder in forward order; empty for Unet
+  int featC[4] = {64, 128, 256, 512};  // channels of the encoder features f2..f5
   int stem = -1, head = -1, CP = 4, CinP = 4;
   long long param_floats = 0, buffer_floats = 0, param_count = 0;
   long long stage_begin[6] = {0, 0, 0, 0, 0, 0};
@@ -116,10 +118,11 @@ static void push_info(uwm_model* m, const std::string& name, int kind, int arena
 
 static int build_model(uwm_model* m) {
   const uwm_unet_desc& d = m->desc;
-  int nb[4];
+  int nb[4]; int expn = 1;
   if (d.encoder == UWM_ENC_RESNET18) { nb[0] = 2; nb[1] = 2; nb[2] = 2; nb[3] = 2; }
   else if (d.encoder == UWM_ENC_RESNET34) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; }
-  else return fail("unsupported encoder %d (supported: resnet18, resnet34)", d.encoder);
+  else if (d.encoder == UWM_ENC_RESNET50) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; expn = 4; }
+  else return fail("unsupported encoder %d (supported: resnet18, resnet34, resnet50)", d.encoder);
   if (d.in_channels < 1 || d.in_channels > 4) return fail("in_channels must be 1..4, got %d", d.in_channels);
   if (d.classes < 1 || d.classes > 4) return fail("classes must be 1..4, got %d", d.classes);
   for (int i = 0; i < 5; ++i)
@@ -135,17 +138,25 @@ static int build_model(uwm_model* m) {
     for (int b = 0; b < nb[s]; ++b) {
       const int stride = (b == 0 && s > 0) ? 2 : 1;
       char pre[64]; snprintf(pre, sizeof(pre), "encoder.layer%d.%d", s + 1, b);
-      BlockL bl;
-      bl.c1 = add_conv(m, std::string(pre) + ".conv1", cin, widths[s], 3, stride, 1, stage, true, std::string(pre) + ".bn1");
-      bl.c2 = add_conv(m, std::string(pre) + ".conv2", widths[s], widths[s], 3, 1, 1, stage, true, std::string(pre) + ".bn2");
+      const std::string P(pre);
+      BlockL bl; bl.stride = stride; bl.Cin = cin; bl.Cout = widths[s] * expn;
+      if (expn == 1) {
+        bl.c1 = add_conv(m, P + ".conv1", cin, widths[s], 3, stride, 1, stage, true, P + ".bn1");
+        bl.c2 = add_conv(m, P + ".conv2", widths[s], widths[s], 3, 1, 1, stage, true, P + ".bn2");
+      } else {            // torchvision Bottleneck v1.5: the stride sits on the 3x3
+        bl.c1 = add_conv(m, P + ".conv1", cin, widths[s], 1, 1, 0, stage, true, P + ".bn1");
+        bl.c2 = add_conv(m, P + ".conv2", widths[s], widths[s], 3, stride, 1, stage, true, P + ".bn2");
+        bl.c3 = add_conv(m, P + ".conv3", widths[s], bl.Cout, 1, 1, 0, stage, true, P + ".bn3");
+      }
       bl.cd = -1;
-      if (stride != 1 || cin != widths[s])
-        bl.cd = add_conv(m, std::string(pre) + ".downsample.0", cin, widths[s], 1, stride, 0, stage, true, std::string(pre) + ".downsample.1");
+      if (stride != 1 || cin != bl.Cout)
+        bl.cd = add_conv(m, P + ".downsample.0", cin, bl.Cout, 1, stride, 0, stage, true, P + ".downsample.1");
       m->stages[s].push_back(bl);
-      cin = widths[s];
+      cin = bl.Cout;
     }
   }
-  const int encc[5] = {512, 256, 128, 64, 64};
+  const int encc[5] = {512 * expn, 256 * expn, 128 * expn, 64 * expn, 64};
+  for (int j = 0; j < 4; ++j) m->featC[j] = encc[3 - j];            // f2..f5
   int prev = encc[0];
   if (d.arch == UWM_ARCH_UNET) {
     for (int i = 0; i < 5; ++i) {
@@ -274,14 +285,16 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   std::vector<int> sh(4), sw(4);
   for (int s = 0; s < 4; ++s) {
     for (auto& bl : m->stages[s]) {
-      const ConvL& c1 = m->convs[bl.c1];
-      h /= c1.stride; w /= c1.stride;
-      const size_t sz = (size_t)N * h * w * c1.Cout;
-      p.y[bl.c1] = alloc(sz); p.y[bl.c2] = alloc(sz);
-      p.oh[bl.c1] = p.oh[bl.c2] = h; p.ow[bl.c1] = p.ow[bl.c2] = w;
-      if (bl.cd >= 0) { p.y[bl.cd] = alloc(sz); p.oh[bl.cd] = h; p.ow[bl.cd] = w; }
+      const int hi = h, wi = w;
+      h /= bl.stride; w /= bl.stride;
+      auto place = [&](int ci, int oh, int ow) { p.y[ci] = alloc((size_t)N * oh * ow * m->convs[ci].Cout); p.oh[ci] = oh; p.ow[ci] = ow; };
+      if (bl.c3 < 0) { place(bl.c1, h, w); place(bl.c2, h, w); }
+      else { place(bl.c1, hi, wi); place(bl.c2, h, w); place(bl.c3, h, w); }
+      if (bl.cd >= 0) place(bl.cd, h, w);
+      const size_t sz = (size_t)N * h * w * bl.Cout;
       p.xn[bi++] = alloc(sz);
       if (sz > max_in) max_in = sz;
+      if ((size_t)N * hi * wi * bl.Cin > max_in) max_in = (size_t)N * hi * wi * bl.Cin;
     }
     sh[s] = h; sw[s] = w;
   }
@@ -313,12 +326,9 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
     bi = 0;
     for (int s = 0; s < 4; ++s)
       for (auto& bl : m->stages[s]) {
-        const ConvL& c1 = m->convs[bl.c1];
-        h /= c1.stride; w /= c1.stride;
-        const size_t sz = (size_t)N * h * w * c1.Cout;
-        p.g[bl.c1] = alloc(sz); p.g[bl.c2] = alloc(sz);
-        if (bl.cd >= 0) p.g[bl.cd] = alloc(sz);
-        p.gx[bi++] = alloc(sz);
+        for (int ci : {bl.c1, bl.c2, bl.c3, bl.cd})
+          if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].Cout);
+        p.gx[bi++] = alloc((size_t)N * p.oh[bl.c2] * p.ow[bl.c2] * bl.Cout);
       }
     p.tmp = alloc(max_in);
     p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
@@ -337,7 +347,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       }
       p.dcat.assign(1, alloc(max_dcat));
       p.gcat = alloc(max_gcat);
-      const int fc[4] = {256, 128, 64, 64};       // gradient accumulators of f4, f3, f2, f1
+      const int fc[4] = {m->featC[2], m->featC[1], m->featC[0], 64};       // gradient accumulators of f4, f3, f2, f1
       p.gskip.assign(4, 0);
       for (int j = 0; j < 4; ++j) p.gskip[j] = alloc((size_t)N * (H >> (4 - j)) * (W >> (4 - j)) * fc[j]);
     }
@@ -512,22 +522,30 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
   size_t bi = 0;
   for (int s = 0; s < 4; ++s) {
     for (auto& bl : m->stages[s]) {
-      const ConvL& c1 = m->convs[bl.c1];
-      const int ho = h / c1.stride, wo = w / c1.stride;
-      if (conv_bn(bl.c1, cur, nullptr, ho, wo)) return 1;
-      Src a1 = lazy_src(c, bl.c1, ho, wo);
-      if (conv_bn(bl.c2, a1, nullptr, ho, wo)) return 1;
-      const BNL& b2 = m->bns[m->convs[bl.c2].bn];
+      const int ho = h / bl.stride, wo = w / bl.stride;
+      if (bl.c3 < 0) {
+        if (conv_bn(bl.c1, cur, nullptr, ho, wo)) return 1;
+        Src a1 = lazy_src(c, bl.c1, ho, wo);
+        if (conv_bn(bl.c2, a1, nullptr, ho, wo)) return 1;
+      } else {
+        if (conv_bn(bl.c1, cur, nullptr, h, w)) return 1;
+        Src a1 = lazy_src(c, bl.c1, h, w);
+        if (conv_bn(bl.c2, a1, nullptr, ho, wo)) return 1;
+        Src a2 = lazy_src(c, bl.c2, ho, wo);
+        if (conv_bn(bl.c3, a2, nullptr, ho, wo)) return 1;
+      }
+      const int lc = bl.last();
+      const BNL& b2 = m->bns[m->convs[lc].bn];
       const float *idp = cur.ptr, *sd = nullptr, *bd = nullptr;
       if (bl.cd >= 0) {
         if (conv_bn(bl.cd, cur, nullptr, ho, wo)) return 1;
         const BNL& bdn = m->bns[m->convs[bl.cd].bn];
         idp = c.F(p.y[bl.cd]); sd = c.F(bdn.f_off) + 2 * bdn.C; bd = c.F(bdn.f_off) + 3 * bdn.C;
       }
-      LCHK(launch_residual(c.F(p.y[bl.c2]), c.F(b2.f_off) + 2 * b2.C, c.F(b2.f_off) + 3 * b2.C, idp, sd, bd,
-                           c.F(p.xn[bi]), (size_t)N * ho * wo, c1.Cout, st));
+      LCHK(launch_residual(c.F(p.y[lc]), c.F(b2.f_off) + 2 * b2.C, c.F(b2.f_off) + 3 * b2.C, idp, sd, bd,
+                           c.F(p.xn[bi]), (size_t)N * ho * wo, bl.Cout, st));
       h = ho; w = wo;
-      cur = mk_src(c.F(p.xn[bi]), c1.Cout, h, w);
+      cur = mk_src(c.F(p.xn[bi]), bl.Cout, h, w);
       ++bi;
     }
     feats[s] = cur;
@@ -596,7 +614,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
   std::vector<size_t> first_blk(4); { size_t b = 0; for (int s = 0; s < 4; ++s) { first_blk[s] = b; b += m->stages[s].size(); } }
   auto feat_src = [&](int s) {      // materialised output of encoder stage s (f2..f5)
     const size_t lb = first_blk[s] + m->stages[s].size() - 1;
-    return mk_src(c.F(p.xn[lb]), m->convs[m->stages[s].back().c1].Cout, sh[s], sw[s]);
+    return mk_src(c.F(p.xn[lb]), m->stages[s].back().Cout, sh[s], sw[s]);
   };
   Src f1 = lazy_src(c, m->stem, h1, w1);
 
@@ -721,20 +739,28 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       const BlockL& bl = m->stages[s][b];
       const size_t bi = first_blk[s] + b;
       const float* dz = c.F(p.gx[bi]);                       // masked grad wrt the block output
-      LCHK(run_bn_bwd(c, bl.c2, dz, c.F(p.g[bl.c2]), npix));
+      const int lc = bl.last();
+      const int hin = h * bl.stride, win = w * bl.stride;
+      LCHK(run_bn_bwd(c, lc, dz, c.F(p.g[lc]), npix));
       if (bl.cd >= 0) LCHK(run_bn_bwd(c, bl.cd, dz, c.F(p.g[bl.cd]), npix));
-      Src a1 = lazy_src(c, bl.c1, h, w);
+      int hc1 = h, wc1 = w;                                  // resolution of c1's output
+      if (bl.c3 >= 0) {                                      // Bottleneck tail: conv3 (1x1) <- relu(bn2(conv2))
+        Src a2 = lazy_src(c, bl.c2, h, w);
+        LCHK(run_wgrad(c, bl.c3, a2, nullptr, c.F(p.g[bl.c3]), h, w));
+        LCHK(run_dgrad(c, bl.c3, c.F(p.g[bl.c3]), h, w, h, w, c.F(p.g[bl.c2]), nullptr, a2.ptr, a2.scale, a2.shift));
+        LCHK(run_bn_bwd(c, bl.c2, c.F(p.g[bl.c2]), c.F(p.g[bl.c2]), npix));
+        hc1 = hin; wc1 = win;
+      }
+      Src a1 = lazy_src(c, bl.c1, hc1, wc1);
       LCHK(run_wgrad(c, bl.c2, a1, nullptr, c.F(p.g[bl.c2]), h, w));
-      LCHK(run_dgrad(c, bl.c2, c.F(p.g[bl.c2]), h, w, h, w, c.F(p.g[bl.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
-      LCHK(run_bn_bwd(c, bl.c1, c.F(p.g[bl.c1]), c.F(p.g[bl.c1]), npix));
+      LCHK(run_dgrad(c, bl.c2, c.F(p.g[bl.c2]), h, w, hc1, wc1, c.F(p.g[bl.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
+      LCHK(run_bn_bwd(c, bl.c1, c.F(p.g[bl.c1]), c.F(p.g[bl.c1]), (size_t)N * hc1 * wc1));
       // block input
-      const ConvL& c1 = m->convs[bl.c1];
-      const int hin = h * c1.stride, win = w * c1.stride;
       Src in; float* gin; const float* in_mask;
-      if (b > 0) { in = mk_src(c.F(p.xn[bi - 1]), c1.CinP, hin, win); gin = c.F(p.gx[bi - 1]); in_mask = in.ptr; }
+      if (b > 0) { in = mk_src(c.F(p.xn[bi - 1]), bl.Cin, hin, win); gin = c.F(p.gx[bi - 1]); in_mask = in.ptr; }
       else if (s > 0) { in = feat_src(s - 1); gin = c.F(p.gx[first_blk[s] - 1]); in_mask = in.ptr; }
       else { in = mk_src(c.F(p.pool), 64, hin, win); gin = c.F(p.g_pool); in_mask = nullptr; }
-      LCHK(run_wgrad(c, bl.c1, in, nullptr, c.F(p.g[bl.c1]), h, w));
+      LCHK(run_wgrad(c, bl.c1, in, nullptr, c.F(p.g[bl.c1]), hc1, wc1));
       const float* addend;
       if (bl.cd >= 0) {
         LCHK(run_wgrad(c, bl.cd, in, nullptr, c.F(p.g[bl.cd]), h, w));
@@ -745,7 +771,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       } else {
         addend = dz;                                         // identity shortcut
       }
-      LCHK(run_dgrad(c, bl.c1, c.F(p.g[bl.c1]), h, w, hin, win, gin, addend, in_mask, nullptr, nullptr));
+      LCHK(run_dgrad(c, bl.c1, c.F(p.g[bl.c1]), hc1, wc1, hin, win, gin, addend, in_mask, nullptr, nullptr));
     }
     if (s == 0) {
       // maxpool backward (+ decoder skip gradient for f1) -> stem BN backward -> stem wgrad
@@ -942,18 +968,7 @@ int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* c
   if (p.N == 0) return fail("uwm_debug_lookup: no plan yet");
   const std::string k(key);
   const int N = p.N, H = p.H, W = p.W;
-  auto conv_geo = [&](int ci, long long* cnt) {
-    // replay the geometry walk
-    int hh = H / 2, ww = W / 2;
-    if (ci == h->stem) { *cnt = (long long)N * hh * ww * 64; return; }
-    hh /= 2; ww /= 2;
-    for (int s = 0; s < 4; ++s) for (auto& bl : h->stages[s]) {
-      const ConvL& c1 = h->convs[bl.c1]; hh /= c1.stride; ww /= c1.stride;
-      if (ci == bl.c1 || ci == bl.c2 || ci == bl.cd) { *cnt = (long long)N * hh * ww * c1.Cout; return; }
-    }
-    for (auto& d : h->dec) { hh *= 2; ww *= 2; if (ci == d.c1 || ci == d.c2) { *cnt = (long long)N * hh * ww * h->convs[d.c1].Cout; return; } }
-    *cnt = 0;
-  };
+  auto conv_geo = [&](int ci, long long* cnt) { *cnt = (long long)N * p.oh[ci] * p.ow[ci] * h->convs[ci].CoutP; };
   if (k.rfind("y:", 0) == 0 || k.rfind("g:", 0) == 0) {
     const std::string name = k.substr(2);
     for (size_t i = 0; i < h->convs.size(); ++i) if (h->convs[i].name == name) {
@@ -965,8 +980,8 @@ int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* c
   auto blk_geo = [&](size_t bi, long long* cnt) {
     int hh = H / 4, ww = W / 4; size_t b = 0;
     for (int s = 0; s < 4; ++s) for (auto& bl : h->stages[s]) {
-      const ConvL& c1 = h->convs[bl.c1]; hh /= c1.stride; ww /= c1.stride;
-      if (b == bi) { *cnt = (long long)N * hh * ww * c1.Cout; return; }
+      hh /= bl.stride; ww /= bl.stride;
+      if (b == bi) { *cnt = (long long)N * hh * ww * bl.Cout; return; }
       ++b;
     }
     *cnt = 0;
