@@ -148,3 +148,24 @@ def test_cli_parses_reference_flags(U):
     import pytest as _pt
     with _pt.raises(SystemExit):
         cli.main(["train", "--epochs", "1", "--batch-size", "2", "--lr", "0.001", "--no-early-stopping", "--synthetic", "8"])
+
+
+def test_workspace_plan_sizes(U):
+    """uwm_workspace_bytes is host-side planning: sizes must stay where DESIGN.md §3 says (a plan regression once
+    allocated the decoder gradients at 8x the resolution) and scale ~linearly with the batch."""
+    import ctypes as C
+    from unet_watermark_amd import _lib as L
+    lib = L.lib()
+    gib = {}
+    for arch in ("Unet", "UnetPlusPlus"):
+        for enc in ("resnet34", "resnet50"):
+            desc = L.uwm_unet_desc(L.ENC[enc], 3, 1, (C.c_int * 5)(256, 128, 64, 32, 16), 1e-5, 0.1, L.ARCH[arch])
+            h = C.c_void_p()
+            L.check(lib.uwm_create(C.byref(desc), C.byref(h)))
+            b1, b16, b64 = (lib.uwm_workspace_bytes(h, n, 512, 512, 1) for n in (1, 16, 64))
+            assert b16 < 16.5 * b1 and b64 < 4.1 * b16, (arch, enc, b1, b16, b64)
+            assert lib.uwm_workspace_bytes(h, 16, 512, 512, 0) < b16
+            gib[(arch, enc)] = b16 / 2 ** 30
+            lib.uwm_destroy(h)
+    assert 6.5 < gib[("Unet", "resnet34")] < 8.5, gib           # BASELINE config 2: ~7.5 GB of the 288 GB
+    assert gib[("UnetPlusPlus", "resnet34")] < 16 and gib[("UnetPlusPlus", "resnet50")] < 30, gib

@@ -330,6 +330,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
           if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].Cout);
         p.gx[bi++] = alloc((size_t)N * p.oh[bl.c2] * p.ow[bl.c2] * bl.Cout);
       }
+    h = H / 32; w = W / 32;                       // deepest feature: the decoder loop below doubles from here
     p.tmp = alloc(max_in);
     p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
     for (size_t i = 0; i < m->dec.size(); ++i) {
