@@ -122,6 +122,12 @@ int  uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, fl
                    float eps, float weight_decay, long long step, float grad_scale, float max_norm, void* scratch,
                    uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
+/* Staged backward under data parallelism: uwm_backward runs its weight-gradient kernels on an internal side stream and,
+ * by default, makes the caller's stream wait for them before it returns.  With a join stream set (the stream the
+ * gradient all-reduces are issued on), the stages before the last make THAT stream wait instead, so the caller's
+ * stream continues into the next stage while the side stream drains; the last stage joins both.  NULL restores the
+ * default. */
+int  uwm_set_join_stream(uwm_handle h, uwm_stream stream);
 /* Input pipeline on the device (src/utils/dataset.py:298-395 get_*_transform tails): uint8 HWC images [N][H][W][C] ->
  * Normalize(mean, std) of x/255 as NCHW fp32 (what uwm_forward takes); uint8 masks [N][H][W] -> (m > threshold) as
  * uint8 {0,1} (what uwm_loss takes).  flags (device int[N] or NULL): bit0 HorizontalFlip, bit1 VerticalFlip, bits 2-3

@@ -64,6 +64,7 @@ SIGNATURES = {
     "uwm_adam_clip": (I, [P, P, P, P, L, F, F, F, F, F, L, F, F, P, P]),
     "uwm_scale": (I, [P, L, F, P]),
     "uwm_set_winograd": (I, [I]),
+    "uwm_set_join_stream": (I, [P, P]),
     "uwm_preprocess_u8": (I, [P, I, I, I, I, C.POINTER(C.c_float), C.POINTER(C.c_float), P, P, P]),
     "uwm_preprocess_mask_u8": (I, [P, I, I, I, I, P, P, P]),
     "uwm_resize_threshold": (I, [P, I, I, I, I, I, I, F, I, P, P, P]),

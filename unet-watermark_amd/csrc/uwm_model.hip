@@ -89,6 +89,7 @@ struct uwm_model {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
   int use_side = 1;
+  hipStream_t join_stream = nullptr;  // uwm_set_join_stream: stream that waits for the side stream at the end of uwm_backward (default: the caller's)
   bool packed_in_fwd = false;         // dgrad weight repacks were enqueued on the side stream by the last forward
 };
 
@@ -785,7 +786,11 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
   }
   if (c.wst != st) {                    // join: the caller's stream waits for every wgrad of these stages
     HIPCHK(hipEventRecord(m->ev_join, c.wst));
-    HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+    // data-parallel training hands in its communication stream: the bucket's all-reduce waits for this stage's weight
+    // gradients, the caller's stream runs on into the next stage's dgrad chain (nothing there reads what the side
+    // stream still writes).  The LAST stage always joins the caller's stream: the optimizer comes next.
+    HIPCHK(hipStreamWaitEvent((m->join_stream && se < 5) ? m->join_stream : st, m->ev_join, 0));
+    if (m->join_stream && se >= 5) HIPCHK(hipStreamWaitEvent(m->join_stream, m->ev_join, 0));
   }
   return 0;
 }
@@ -1022,6 +1027,10 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st) {
 }
 static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad) {
   return kh == 3 && kw == 3 && stride == 1 && pad == 1 && (a.Ctot & 7) == 0 && (a.C0 & 7) == 0 && a.Ho >= 8 && a.Wo >= 16;
+}
+int uwm_set_join_stream(uwm_handle h, uwm_stream stream) {
+  if (!h) return fail("uwm_set_join_stream: null handle");
+  h->join_stream = (hipStream_t)stream; return 0;
 }
 int uwm_set_winograd(int on) { winograd_set_mode(on < 0 ? 0 : (on > 2 ? 1 : on)); return 0; }
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }

@@ -177,6 +177,10 @@ class Trainer:
         if self.ddp:
             if self._reducer is None or self._reducer.flat.data_ptr() != m.flat_grads().data_ptr():
                 self._reducer = GradReducer(m.flat_grads(), m.stages, self.group, force=self._force)
+                if self.overlap and self._reducer.comm_stream is not None:
+                    # each stage's weight gradients (library side stream) gate that stage's all-reduce on the
+                    # communication stream instead of stalling the compute stream at every stage boundary
+                    L.check(L.lib().uwm_set_join_stream(m._h, C.c_void_p(self._reducer.comm_stream.cuda_stream)))
             if self.overlap:
                 for k in range(nst):
                     m._backward_raw(self._dl, k, k + 1)
