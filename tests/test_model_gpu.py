@@ -391,6 +391,30 @@ def test_cli_train_on_synthetic_learns(cuda, tmp_path):
     assert "encoder.conv1.weight" in ck["model_state_dict"] and ck["config"]["MODEL"]["ENCODER_NAME"] == "resnet18"
 
 
+def test_cli_train_unetplusplus_and_predictor(cuda, tmp_path):
+    """the reference's default MODEL.NAME end to end: `main.py train --model UnetPlusPlus`, checkpoint keys, then the
+    hipGraph-replayed predictor on that checkpoint's architecture."""
+    from unet_watermark_amd import cli
+    hist = cli.main(["train", "--epochs", "2", "--batch-size", "4", "--lr", "0.002", "--no-early-stopping",
+                     "--synthetic", "16", "--img-size", "64", "--encoder", "resnet18", "--workers", "0", "--model", "UnetPlusPlus",
+                     "--model-save-path", str(tmp_path / "pp.pth")])
+    assert len(hist) == 2 and all(h["train_loss"] == h["train_loss"] for h in hist)
+    from unet_watermark_amd.checkpoint import load_checkpoint
+    ck = load_checkpoint(str(tmp_path / "pp.pth"))
+    assert "decoder.blocks.x_0_4.conv2.0.weight" in ck["model_state_dict"] and ck["config"]["MODEL"]["NAME"] == "UnetPlusPlus"
+    import unet_watermark_amd as U
+    from unet_watermark_amd.predict import WatermarkPredictor
+    m = U.UnetPlusPlus("resnet18").to(cuda)
+    m.load_state_dict(ck["model_state_dict"])
+    pred = WatermarkPredictor(model=m, device=cuda)
+    g = torch.Generator().manual_seed(1)
+    img = torch.randint(0, 256, (2, 64, 64, 3), generator=g, dtype=torch.uint8)
+    x = pred.preprocess(img)
+    a = pred.logits(x, use_graph=True).clone()
+    b = pred.logits(x, use_graph=False)
+    assert torch.equal(a, b)
+
+
 def test_bench_ddp_path_single_rank_rccl(cuda):
     """The data-parallel step (RCCL all-reduce of 5 gradient buckets on a side stream, overlapped with the staged
     backward) run through torch.distributed.run with ONE rank: same loss as the plain single-GPU step."""
