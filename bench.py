@@ -70,6 +70,7 @@ def main():
                     help="Unet = BASELINE.json's configs (headline); UnetPlusPlus = the reference's default MODEL.NAME (SURVEY 8 f3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
+    ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) that carry per-launch HIP events")
     ap.add_argument("--serial-steps", type=int, default=3,
                     help="extra UNTIMED steps after the timed region with the wgrad side stream off, to report the "
                          "dominant kernel's un-overlapped launch time next to the overlapped one (0 = skip)")
@@ -102,7 +103,7 @@ def main():
     torch.manual_seed(42)                                  # identical init on every rank (+ broadcast in Trainer)
     model = getattr(U, args.arch)(args.encoder, encoder_weights=None, in_channels=3, classes=1).to(dev)
     trainer = Trainer(model, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-4, weight_decay=1e-4,
-                      overlap_comm=not args.no_overlap, force_ddp=force_ddp)
+                      overlap_comm=not args.no_overlap, force_ddp=force_ddp and not os.environ.get("UWM_PG_ONLY"))
     g = torch.Generator(device="cpu").manual_seed(42 + rank)      # rank-distinct synthetic data
     n, s = args.batch, args.size
     x = torch.randn(n, 3, s, s, generator=g).to(dev)
@@ -122,9 +123,13 @@ def main():
     for _ in range(args.warmup):
         loss = trainer.step(x, t)
     barrier()
-    L.lib().uwm_prof_enable(1)
+    # per-launch HIP events (uwm_prof_*) cost ~0.7 ms per step (two timestamped barrier packets per conv launch), so
+    # they are recorded for the LAST `prof_steps` steps of the timed region only; `kernels` / `roofline` come from those
+    prof_steps = min(args.prof_steps, args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - prof_steps:
+            L.lib().uwm_prof_enable(1)
         loss = trainer.step(x, t)
     barrier()
     dt = time.perf_counter() - t0
@@ -160,8 +165,8 @@ def main():
             cnt, ms, fl = prof[c * 3], prof[c * 3 + 1], prof[c * 3 + 2]
             if cnt > 0:
                 name = L.lib().uwm_prof_class_name(c).decode()
-                ent = {"kernel": name, "launches_per_step": cnt / args.steps,
-                       "avg_us": round(1e3 * ms / cnt, 2), "ms_per_step": round(ms / args.steps, 3),
+                ent = {"kernel": name, "launches_per_step": cnt / max(1, prof_steps),
+                       "avg_us": round(1e3 * ms / cnt, 2), "ms_per_step": round(ms / max(1, prof_steps), 3),
                        "tflops": round(fl / ms / 1e9, 2)}
                 if "wino" in name:      # Winograd F(2x2,3x3): 16 MFMA multiplies per 36 direct ones
                     ent["mfma_executed_tflops"] = round(fl / ms / 1e9 / WINO_RATIO, 2)
@@ -218,7 +223,8 @@ def main():
                                "unoverlapped": serial,
                                "all_conv_kernels": {"tflops": round(tot_fl / tot_ms / 1e9, 2),
                                                     "frac": round(tot_fl / tot_ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
-                                                    "share_of_step": round(tot_ms / args.steps / ms_step, 4)}}
+                                                    "share_of_step": round(tot_ms / max(1, prof_steps) / ms_step, 4)},
+                               "profiled_steps": f"last {prof_steps} of the {args.steps} timed steps"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch)
         print(json.dumps(out), flush=True)

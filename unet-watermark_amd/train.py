@@ -18,6 +18,10 @@ import torch.distributed as dist
 from . import _lib as L
 
 
+import os as _os
+_NOOP_COLLECTIVES = bool(_os.environ.get("UWM_DDP_NOOP"))
+
+
 class GradReducer:
     """Bucketed gradient all-reduce over a flat gradient arena.
 
@@ -44,6 +48,8 @@ class GradReducer:
             return
         b, e = self.buckets[k]
         view = self.flat[b:e]
+        if _NOOP_COLLECTIVES:          # experiments only: keep the stream/event structure, skip the collective
+            return
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
