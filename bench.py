@@ -21,6 +21,13 @@ import os
 import sys
 import time
 
+# The library overlaps its weight-gradient kernels on a second HIP stream.  ROCm multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; once torch.distributed's RCCL group has
+# created its streams, the library's side stream lands on the compute stream's queue and the overlap is lost
+# (measured: 632 vs 668 img/s on the data-parallel path, profiles/r01 notes in DESIGN.md 6).  Must be set before
+# the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -98,7 +105,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="nccl", **({} if os.environ.get("UWM_PG_LAZY") else {"device_id": dev}))
 
     torch.manual_seed(42)                                  # identical init on every rank (+ broadcast in Trainer)
     model = getattr(U, args.arch)(args.encoder, encoder_weights=None, in_channels=3, classes=1).to(dev)

@@ -11,6 +11,10 @@ import subprocess
 import sys
 from pathlib import Path
 
+# more hardware queues than ROCm's default 4, so the library's side stream does not alias the compute stream's queue
+# once RCCL / other libraries have created their own streams (effective only if the HIP runtime is not up yet)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
