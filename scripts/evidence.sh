@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-T=r01_j
+T=${1:-r01_l}
 timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_gpu_tests.log; tail -3 gpurun_out/${T}_gpu_tests.log
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -o s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${T}_stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_fetch/x -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_fetch.log 2>&1
@@ -10,3 +10,7 @@ python scripts/pmc_summary.py gpurun_out/${T}_fetch gpurun_out/${T}_write gpurun
 cp profiles/${T}_pmc_summary.json profiles/pmc_traffic.json gpurun_out/
 timeout -k 10 600 python bench.py > gpurun_out/${T}_bench_1gpu.json 2> gpurun_out/${T}_bench.err; tail -c 600 gpurun_out/${T}_bench_1gpu.json
 timeout -k 10 300 python bench_predict.py > gpurun_out/${T}_bench_predict.json 2>/dev/null; tail -c 400 gpurun_out/${T}_bench_predict.json
+timeout -k 10 400 python bench.py --arch UnetPlusPlus --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_bench_unetplusplus.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_unetplusplus.json
+timeout -k 10 400 python bench.py --encoder resnet50 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_bench_resnet50.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_resnet50.json
+UWM_FORCE_DDP=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_bench_ddp_1rank.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_ddp_1rank.json
+timeout -k 10 300 python scripts/logit_error.py resnet34 2 256 256 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_logit_error.txt; cat gpurun_out/${T}_logit_error.txt
