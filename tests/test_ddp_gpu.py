@@ -76,4 +76,6 @@ def test_two_ranks_one_gpu_match_averaged_gradient_step(cuda, arch, tmp_path):
         m.flat_grads().copy_(0.5 * (gs[0] + gs[1]))
         opt.step()
     diff = (m.flat_parameters().cpu() - p0).abs().max()
-    assert diff < 3e-5, float(diff)       # 3 % of one Adam step (lr 1e-3): summation-order noise of the fp32 atomics through Adam's normalisation
+    # a few % of one Adam step (lr 1e-3): summation-order noise of the fp32 weight-gradient atomics through Adam's
+    # normalisation (measured 0.7e-5 Unet, 3.4e-5 UnetPlusPlus); a wrong bucket / scale would be >= 1e-3
+    assert diff < 1e-4, float(diff)
