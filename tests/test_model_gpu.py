@@ -137,6 +137,31 @@ def test_resnet50_bottleneck_encoder_parity(cuda, arch, n, h, w):
         assert (m(x.to(cuda)).cpu() - ref(x)).abs().max() < LOGIT_TOL
 
 
+@pytest.mark.parametrize("fwd_mode,bwd_mode", [(0, 0), (1, 0), (0, 1)])
+def test_direct_kernels_and_winograd_switch_between_forward_and_backward(cuda, fwd_mode, bwd_mode):
+    """uwm_set_winograd(0) = the direct kernels everywhere (dcat + upsplit decoder backward, packed dgrad banks for every
+    layer); switching the mode BETWEEN a forward and its backward must re-derive the dgrad filter banks instead of
+    using the ones the forward prepared for the other mode."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd import _lib as L
+    from oracle import unet_oracle as O
+    m, ref = _pair("resnet18", dev=cuda)
+    x, t = O.synthetic_batch(4, 128, 160, seed=21)
+    m.train(); ref.train()
+    crit_ref = O.DiceLoss(smooth=1e-5); crit = U.DiceLoss(mode="binary", smooth=1e-5)
+    out_ref = ref(x); crit_ref(out_ref, t.unsqueeze(1)).backward()
+    try:
+        L.lib().uwm_set_winograd(fwd_mode)
+        out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda))
+        L.lib().uwm_set_winograd(bwd_mode)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        L.lib().uwm_set_winograd(1)
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    _grad_check(m, ref)
+
+
 def test_unetplusplus_trainer_steps_match_oracle(cuda):
     """three fused Trainer steps (forward, Dice, staged backward, Adam) of UnetPlusPlus track the oracle's."""
     import unet_watermark_amd as U

@@ -91,6 +91,7 @@ struct uwm_model {
   int use_side = 1;
   hipStream_t join_stream = nullptr;  // uwm_set_join_stream: stream that waits for the side stream at the end of uwm_backward (default: the caller's)
   bool packed_in_fwd = false;         // dgrad weight repacks were enqueued on the side stream by the last forward
+  int pack_mode = -1;                 // uwm_set_winograd mode those repacks were made for
 };
 
 static int add_bn(uwm_model* m, const std::string& name, int C, int stage) {
@@ -501,7 +502,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     }
     LCHK(wino_jobs(c, true, m->side));
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
-    m->packed_in_fwd = true;
+    m->packed_in_fwd = true; m->pack_mode = winograd_mode();
   }
   LCHK(wino_jobs(c, false, st));
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
@@ -624,9 +625,10 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
     HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
-    if (m->packed_in_fwd) {
+    if (m->packed_in_fwd && m->pack_mode == winograd_mode()) {      // (a mode switch between forward and backward: redo them)
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
     } else {
+      if (m->packed_in_fwd) HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));     // stale packs must have landed before they are overwritten
       for (size_t ci = 0; ci < m->convs.size(); ++ci) {
         const ConvL& cv = m->convs[ci];
         if (cv.dgrad && (!(cv.wud_off && p.wino_ok(ci)) || cv.CoutP == 16))
