@@ -162,6 +162,26 @@ def test_direct_kernels_and_winograd_switch_between_forward_and_backward(cuda, f
     _grad_check(m, ref)
 
 
+@pytest.mark.parametrize("arch,dec", [("Unet", (128, 64, 32, 16, 8)), ("UnetPlusPlus", (128, 64, 32, 16, 8)),
+                                      ("UnetPlusPlus", (64, 48, 40, 24, 12))])
+def test_custom_decoder_channels(cuda, arch, dec):
+    """MODEL.DECODER_CHANNELS other than smp's default (unet_watermark_large.yaml overrides them): channel wiring of
+    both decoders, channel counts that are not multiples of 16/32 (kernel fall-backs)."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    m, ref = _pair("resnet18", dev=cuda, arch=arch, decoder_channels=dec)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    assert all(m.state_dict()[k].shape == v.shape for k, v in ref.state_dict().items())
+    x, t = O.synthetic_batch(4, 128, 128, seed=31)
+    m.train(); ref.train()
+    crit_ref = O.DiceLoss(smooth=1e-5); crit = U.DiceLoss(mode="binary", smooth=1e-5)
+    out_ref = ref(x); loss_ref = crit_ref(out_ref, t.unsqueeze(1)); loss_ref.backward()
+    out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda)); loss.backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    _grad_check(m, ref)
+
+
 def test_unetplusplus_trainer_steps_match_oracle(cuda):
     """three fused Trainer steps (forward, Dice, staged backward, Adam) of UnetPlusPlus track the oracle's."""
     import unet_watermark_amd as U

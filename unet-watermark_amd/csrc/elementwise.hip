@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mean, const float* rstd, double* dgamma,
                                 double* dbeta, size_t npix, int C, hipStream_t st) {
   const int CW = C > 1024 ? 1024 : C;
-  if ((C & 3) || (C % CW) || (256 % (CW / 4))) return hipErrorInvalidValue;
+  if ((C & 3) || (C % CW) || CW / 4 > 256) return hipErrorInvalidValue;     // any channel count that is a multiple of 4: idle tail threads
   const int tr = 256 / (CW / 4);
   unsigned nb = nblocks(npix, tr * 8);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CW), dim3(256), 0, st, g, y, mean, rstd, dgamma, dbeta, npix, C);
