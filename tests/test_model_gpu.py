@@ -478,17 +478,21 @@ def test_bench_ddp_path_single_rank_rccl(cuda):
     assert abs(a["loss"] - b["loss"]) < 1e-4 and a["value"] > 0
 
 
-@pytest.mark.parametrize("enc,n,h,w,train", [
-    ("resnet18", 3, 32, 64, False),     # minimum height: layer4 is 1x2 pixels (igemm fallbacks everywhere)
-    ("resnet18", 1, 32, 32, False),     # 1x1 bottleneck, batch 1
-    ("resnet18", 5, 96, 160, True),     # odd batch, W/32 = 5
-    ("resnet34", 1, 224, 224, True),    # H/32 = 7: partial 8x16 tiles on every level
-    ("resnet18", 2, 64, 416, True),     # wide strip
+@pytest.mark.parametrize("arch,enc,n,h,w,train", [
+    ("Unet", "resnet18", 3, 32, 64, False),     # minimum height: layer4 is 1x2 pixels (igemm fallbacks everywhere)
+    ("Unet", "resnet18", 1, 32, 32, False),     # 1x1 bottleneck, batch 1
+    ("Unet", "resnet18", 5, 96, 160, True),     # odd batch, W/32 = 5
+    ("Unet", "resnet34", 1, 224, 224, True),    # H/32 = 7: partial 8x16 tiles on every level
+    ("Unet", "resnet18", 2, 64, 416, True),     # wide strip
+    ("UnetPlusPlus", "resnet18", 1, 32, 32, False),
+    ("UnetPlusPlus", "resnet18", 5, 96, 160, True),    # odd feature maps: fused concat split and dcat fallback mixed
+    ("UnetPlusPlus", "resnet34", 1, 224, 224, True),
+    ("Unet", "resnet50", 3, 96, 160, True),
 ])
-def test_shape_sweep_forward_and_gradient_direction(cuda, enc, n, h, w, train):
+def test_shape_sweep_forward_and_gradient_direction(cuda, arch, enc, n, h, w, train):
     import unet_watermark_amd as U
     from oracle import unet_oracle as O
-    m, ref = _pair(enc, dev=cuda, seed=5)
+    m, ref = _pair(enc, dev=cuda, seed=5, arch=arch)
     x, t = O.synthetic_batch(n, h, w, seed=21)
     if not train:
         m.eval(); ref.eval()
@@ -499,7 +503,7 @@ def test_shape_sweep_forward_and_gradient_direction(cuda, enc, n, h, w, train):
     out_ref = ref(x); O.DiceLoss(smooth=1e-5)(out_ref, t.unsqueeze(1)).backward()
     out = m(x.to(cuda)); U.DiceLoss(smooth=1e-5)(out, t.unsqueeze(1).to(cuda)).backward()
     assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
-    _grad_check(m, ref, l2_rel=6e-2, cos_min=0.998)
+    _grad_check(m, ref, l2_rel=(1e-1 if enc == "resnet50" else 6e-2), cos_min=(0.995 if enc == "resnet50" else 0.998))
 
 
 def test_in_channels_1_and_custom_decoder(cuda):
