@@ -276,9 +276,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino8_kernel(const ConvArgs a) {
 bool conv_wino8_applicable(const ConvArgs& a) {
   if (!conv_wino_applicable(a) || a.Cout < 64 || a.Ho < kT8 || a.Wo < kT8) return false;
   // Measured (r01): 3-5 % faster than conv_wino_kernel<4> launch for launch, but its 87-KB / 512-thread workgroups
-  // co-reside worse with the weight-gradient kernels of the side stream: the overlapped train step is 2 % SLOWER
-  // (580 vs 590 img/s).  Selected only on request (uwm_set_winograd(2), force_cfg 308).
-  return winograd_mode() == 2;
+  // co-reside worse with the weight-gradient kernels of the side stream: with EVERY eligible launch on it the
+  // overlapped train step is 2 % slower (580 vs 590 img/s).  So: forward convolutions only (nothing runs beside them),
+  // dgrads stay on the 4-wave kernel; uwm_set_winograd(2) / force_cfg 308 select it wherever the shape allows.
+  if (winograd_mode() == 2) return true;
+  const long wgs = (long)a.N * ((a.Ho + kT8 - 1) / kT8) * ((a.Wo + kT8 - 1) / kT8) * ((a.Cout + 63) / 64);
+  return a.rmul == 1 && wgs >= 256;      // one 512-thread workgroup per CU: fewer would leave CUs idle
 }
 
 hipError_t launch_conv_wino8(const ConvArgs& a, hipStream_t st) {
