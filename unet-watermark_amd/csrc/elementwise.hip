@@ -217,11 +217,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   f4 sg = {0, 0, 0, 0}, sgy = {0, 0, 0, 0};
   if (rx < tr) {
     const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c);
-    for (size_t p = (size_t)blockIdx.x * tr + rx; p < npix; p += (size_t)gridDim.x * tr) {
-      const f4 gv = *(const f4*)(g + p * C + c);
-      const f4 yh = (*(const f4*)(y + p * C + c) - mu) * rs;
-      sg += gv; sgy += gv * yh;
+    // sum g and sum g*y per channel (four 16-byte loads of each tensor in flight); yhat = (y-mu)*rs is applied to the sums
+    const size_t ps = (size_t)gridDim.x * tr;
+    size_t p = (size_t)blockIdx.x * tr + rx;
+    f4 s2 = {0, 0, 0, 0};
+    for (; p + 3 * ps < npix; p += 4 * ps) {
+      const f4 g0 = *(const f4*)(g + p * C + c), g1 = *(const f4*)(g + (p + ps) * C + c), g2 = *(const f4*)(g + (p + 2 * ps) * C + c),
+               g3 = *(const f4*)(g + (p + 3 * ps) * C + c);
+      const f4 y0 = *(const f4*)(y + p * C + c), y1 = *(const f4*)(y + (p + ps) * C + c), y2 = *(const f4*)(y + (p + 2 * ps) * C + c),
+               y3 = *(const f4*)(y + (p + 3 * ps) * C + c);
+      sg += (g0 + g1) + (g2 + g3);
+      s2 += (g0 * (y0 - mu) + g1 * (y1 - mu)) + (g2 * (y2 - mu) + g3 * (y3 - mu));
     }
+    for (; p < npix; p += ps) {
+      const f4 gv = *(const f4*)(g + p * C + c);
+      sg += gv; s2 += gv * (*(const f4*)(y + p * C + c) - mu);
+    }
+    sgy = s2 * rs;
   }
   float* r = red + threadIdx.x * 8;
   r[0] = sg.x; r[1] = sg.y; r[2] = sg.z; r[3] = sg.w; r[4] = sgy.x; r[5] = sgy.y; r[6] = sgy.z; r[7] = sgy.w;
@@ -250,22 +262,40 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
   if (blockIdx.x == 0 && gamma_grad) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) { gamma_grad[c] = (float)dgamma[c]; beta_grad[c] = (float)dbeta[c]; }
   }
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((i * 4) % (size_t)C);
-    const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), gm = *(const f4*)(gamma + c);
-    f4 dg, db;
-    dg.x = (float)dgamma[c] * invM; dg.y = (float)dgamma[c + 1] * invM; dg.z = (float)dgamma[c + 2] * invM; dg.w = (float)dgamma[c + 3] * invM;
-    db.x = (float)dbeta[c] * invM; db.y = (float)dbeta[c + 1] * invM; db.z = (float)dbeta[c + 2] * invM; db.w = (float)dbeta[c + 3] * invM;
-    const f4 yh = (*(const f4*)(y + i * 4) - mu) * rs;
-    const f4 gv = *(const f4*)(g + i * 4);
-    *(f4*)(dy + i * 4) = gm * rs * (gv - db - yh * dg);
+  // dy = gm*rs*(g - db - (y-mu)*rs*dg) = A*g + B*y + K per channel; the grid stride is a multiple of C/4, so a thread
+  // keeps ONE channel quad: coefficients computed once, four 16-byte loads of each tensor in flight per iteration
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % (size_t)C);
+  const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), gm = *(const f4*)(gamma + c);
+  f4 dg, db;
+  dg.x = (float)dgamma[c] * invM; dg.y = (float)dgamma[c + 1] * invM; dg.z = (float)dgamma[c + 2] * invM; dg.w = (float)dgamma[c + 3] * invM;
+  db.x = (float)dbeta[c] * invM; db.y = (float)dbeta[c + 1] * invM; db.z = (float)dbeta[c + 2] * invM; db.w = (float)dbeta[c + 3] * invM;
+  const f4 A = gm * rs, B = -(gm * rs * rs * dg), K = -(A * db) - B * mu;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f4 g0 = *(const f4*)(g + i * 4), g1 = *(const f4*)(g + (i + stride) * 4), g2 = *(const f4*)(g + (i + 2 * stride) * 4),
+             g3 = *(const f4*)(g + (i + 3 * stride) * 4);
+    const f4 y0 = *(const f4*)(y + i * 4), y1 = *(const f4*)(y + (i + stride) * 4), y2 = *(const f4*)(y + (i + 2 * stride) * 4),
+             y3 = *(const f4*)(y + (i + 3 * stride) * 4);
+    *(f4*)(dy + i * 4) = A * g0 + B * y0 + K;
+    *(f4*)(dy + (i + stride) * 4) = A * g1 + B * y1 + K;
+    *(f4*)(dy + (i + 2 * stride) * 4) = A * g2 + B * y2 + K;
+    *(f4*)(dy + (i + 3 * stride) * 4) = A * g3 + B * y3 + K;
   }
+  for (; i < n4; i += stride) *(f4*)(dy + i * 4) = A * *(const f4*)(g + i * 4) + B * *(const f4*)(y + i * 4) + K;
 }
 hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                                const double* dgamma, const double* dbeta, float* dy, float* gamma_grad, float* beta_grad,
                                size_t npix, int C, hipStream_t st) {
   const size_t n4 = npix * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, g, y, mean, rstd, gamma, dgamma,
+  // grid stride (blocks x 256) must be a multiple of C/4 so that every thread stays on one channel quad
+  unsigned nb = nblocks(n4, 256 * 4);
+  const unsigned q = (unsigned)(C / 4);
+  unsigned unit = q;                               // smallest block count with (nb*256) % q == 0: q / gcd(q, 256)
+  { unsigned a = q, b = 256; while (b) { unsigned t = a % b; a = b; b = t; } unit = q / a; }
+  nb = ((nb + unit - 1) / unit) * unit;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, st, g, y, mean, rstd, gamma, dgamma,
                      dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix));
   return hipGetLastError();
 }
