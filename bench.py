@@ -61,8 +61,30 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
         O.train_step(model, crit, opt, x, t)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(bs * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{arch}-{encoder} {hw}x{hw} bs{bs} fwd+Dice+bwd+Adam on torch-CPU fp32 oracle, 1 warm-up + {n} timed steps"}
+    out = {"value": round(bs * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{arch}-{encoder} {hw}x{hw} bs{bs} fwd+Dice+bwd+Adam on torch-CPU fp32 oracle, 1 warm-up + {n} timed steps"}
+    # BASELINE.json's metric also names "mask IoU vs CPU ref": masks (logit > 0) of the sample batch from IDENTICAL
+    # weights on both paths (train-mode BatchNorm).  Not compared after optimizer steps: Adam (eps 1e-8) turns the
+    # zero-mean gradient noise of BatchNorm-invariant weight directions into +-lr steps, so any two fp32
+    # implementations — two runs of torch itself with different thread counts included — walk apart.
+    try:
+        import unet_watermark_amd as U
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ref0 = O.build(encoder, seed=42, arch=arch)
+        hm = getattr(U, arch)(encoder).to(dev)
+        hm.load_state_dict(ref0.state_dict())
+        hm.train(); ref0.train()
+        with torch.no_grad():
+            lg = hm(x.to(dev)).cpu()
+            lr_ = ref0(x)
+        a, b = lg > 0, lr_ > 0
+        inter, union = float((a & b).sum()), float((a | b).sum())
+        out["mask_iou_vs_cpu_ref"] = round(inter / union, 6) if union else 1.0
+        out["logit_max_abs_err_vs_cpu_ref"] = float(f"{float((lg - lr_).abs().max()):.3e}")
+    except Exception as e:                      # never let the checker break the bench line
+        out["mask_iou_vs_cpu_ref"] = None
+        out["mask_note"] = f"not computed: {type(e).__name__}: {e}"
+    return out
 
 
 def main():
