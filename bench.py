@@ -74,13 +74,21 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
         hm = getattr(U, arch)(encoder).to(dev)
         hm.load_state_dict(ref0.state_dict())
         hm.train(); ref0.train()
-        with torch.no_grad():
-            lg = hm(x.to(dev)).cpu()
-            lr_ = ref0(x)
+        cr, ch = O.DiceLoss(smooth=1e-5), U.DiceLoss(mode="binary", smooth=1e-5)
+        o_ref = ref0(x); l_ref = cr(o_ref, t.unsqueeze(1)); l_ref.backward()
+        o_hip = hm(x.to(dev)); l_hip = ch(o_hip, t.unsqueeze(1).to(dev)); l_hip.backward()
+        lg, lr_ = o_hip.detach().cpu(), o_ref.detach()
         a, b = lg > 0, lr_ > 0
         inter, union = float((a & b).sum()), float((a | b).sum())
         out["mask_iou_vs_cpu_ref"] = round(inter / union, 6) if union else 1.0
         out["logit_max_abs_err_vs_cpu_ref"] = float(f"{float((lg - lr_).abs().max()):.3e}")
+        out["loss_abs_diff_vs_cpu_ref"] = float(f"{abs(float(l_hip.detach()) - float(l_ref.detach())):.3e}")
+        gref = dict(ref0.named_parameters()); cmin = 1.0
+        for name, p_ in hm.named_parameters():
+            g1, g2 = p_.grad.detach().cpu().double().flatten(), gref[name].grad.double().flatten()
+            if float(g2.norm()) > 0 and float(g1.norm()) > 0:
+                cmin = min(cmin, float(g1 @ g2 / (g1.norm() * g2.norm())))
+        out["min_grad_cosine_vs_cpu_ref"] = round(cmin, 6)
     except Exception as e:                      # never let the checker break the bench line
         out["mask_iou_vs_cpu_ref"] = None
         out["mask_note"] = f"not computed: {type(e).__name__}: {e}"

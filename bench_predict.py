@@ -30,11 +30,17 @@ def main():
     dt = time.perf_counter() - t0
     fwd, _ = conv_flops(a.encoder, a.size, a.size)
     n = a.batch * a.batches
+    # per-image equality of the batched, graph-replayed path with the batch-1 eager path
+    lb = pred.logits(x, use_graph=not a.no_graph).clone()
+    eq = True
+    for i in (0, a.batch // 2, a.batch - 1):
+        eq = eq and bool(torch.equal(pred.logits(x[i:i + 1], use_graph=False)[0], lb[i]))
     print(json.dumps({"metric": "predict_images_per_sec", "value": round(n / dt, 2), "unit": "images/s", "n_gpus": 1,
                       "images": n, "batch": a.batch, "ms_per_batch": round(1e3 * dt / a.batches, 3), "dtype": "f32",
                       "data": "synthetic", "hipgraph": not a.no_graph,
                       "config": {"workload": f"Unet-{a.encoder} {a.size}x{a.size} eval forward + logit threshold, bs{a.batch} (BASELINE configs[4])"},
-                      "model_tflops": round(n * fwd / dt / 1e12, 2), "mask_positive_frac": round(float((m > 0).float().mean()), 4)}))
+                      "model_tflops": round(n * fwd / dt / 1e12, 2), "mask_positive_frac": round(float((m > 0).float().mean()), 4),
+                      "bitwise_equal_to_batch1_path": eq}))
 
 
 if __name__ == "__main__":
