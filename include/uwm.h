@@ -37,7 +37,8 @@ extern "C" {
 typedef struct uwm_model* uwm_handle;
 typedef void* uwm_stream;              /* hipStream_t */
 
-enum { UWM_ENC_RESNET18 = 18, UWM_ENC_RESNET34 = 34, UWM_ENC_RESNET50 = 50 };   /* 50: Bottleneck blocks (unet_watermark_large.yaml) */
+enum { UWM_ENC_RESNET18 = 18, UWM_ENC_RESNET34 = 34, UWM_ENC_RESNET50 = 50,     /* 50: Bottleneck blocks (unet_watermark_large.yaml) */
+       UWM_ENC_EFFICIENTNET_B4 = 104 };   /* MBConv blocks (README.md:173-176 / BASELINE config 4) */
 enum { UWM_ARCH_UNET = 0, UWM_ARCH_UNETPLUSPLUS = 1 };   /* smp.Unet | smp.UnetPlusPlus (the reference's default MODEL.NAME, src/configs/config.py:15) */
 enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* target dtypes */
 enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
@@ -46,7 +47,7 @@ enum { UWM_ARENA_PARAM = 0, UWM_ARENA_BUFFER = 1 };
 
 /* mirrors smp.Unet(encoder_name, encoder_depth=5, decoder_channels, in_channels, classes) */
 typedef struct {
-  int encoder;                 /* UWM_ENC_RESNET18 | UWM_ENC_RESNET34 | UWM_ENC_RESNET50 */
+  int encoder;                 /* UWM_ENC_* */
   int in_channels;             /* 1..4 */
   int classes;                 /* >= 1 */
   int decoder_channels[5];     /* e.g. 256,128,64,32,16 ; each a multiple of 4 */
@@ -142,6 +143,13 @@ int  uwm_preprocess_mask_u8(const uint8_t* masks, int N, int H, int W, int thres
  * everywhere; 2 (tests) prefers the 512-thread Winograd variant wherever its shape rules allow, whatever the
  * launch size.  Process-wide; also UWM_WINOGRAD=0 in the environment. */
 int  uwm_set_winograd(int on);
+/* EfficientNet encoders only: stochastic depth ("drop connect") of the MBConv blocks in training mode.  `rowscale` is a
+ * device array [uwm_num_mbconv_blocks][N] holding, per block and sample, keep/(1 - p_block) with keep in {0,1}; the host
+ * draws it each step (uwm_mbconv_drop_rate gives p_block; blocks without identity skip ignore their row).  NULL (the
+ * default) disables it.  The pointer is read by the next uwm_forward(training=1) and its uwm_backward. */
+int  uwm_set_drop_connect(uwm_handle h, const float* rowscale);
+int  uwm_num_mbconv_blocks(uwm_handle h);
+float uwm_mbconv_drop_rate(uwm_handle h, int block);
 /* predict.py:620-625 on the device: bilinear resize (cv2.INTER_LINEAR convention) of each image's logit plane
  * [N][h][w] (element stride ld) to [N][H][W], then (v > threshold) ? 255 : 0.  mask and/or resized may be NULL. */
 int  uwm_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float threshold,

@@ -127,6 +127,101 @@ class ResNetEncoder(nn.Module):
         return [f0, f1, f2, f3, f4, f5]
 
 
+# ----------------------------------------------------------------------------- EfficientNet-b4 encoder (config 4)
+# efficientnet_pytorch (vendored by smp) restated: SURVEY.md Appendix A.7.  [smp-knowledge; source not in the container]
+_EFFB4_STAGES = [  # (repeats, kernel, stride, expand, in_ch, out_ch) after width 1.4 / depth 1.8 scaling
+    (2, 3, 1, 1, 48, 24), (4, 3, 2, 6, 24, 32), (4, 5, 2, 6, 32, 56), (6, 3, 2, 6, 56, 112),
+    (6, 5, 1, 6, 112, 160), (8, 5, 2, 6, 160, 272), (2, 3, 1, 6, 272, 448)]
+_EFFB4_IMAGE = 380            # global_params.image_size: the STATIC "same" paddings are computed along this size chain
+
+
+def _static_same_pad(size, k, s):
+    """Conv2dStaticSamePadding: total = max((ceil(size/s)-1)*s + k - size, 0) -> (begin, end) = (t//2, t - t//2)."""
+    o = -(-size // s)
+    t = max((o - 1) * s + k - size, 0)
+    return t // 2, t - t // 2, o
+
+
+class _SamePadConv(nn.Conv2d):
+    """Conv2dStaticSamePadding: a Conv2d (state_dict key `<name>.weight`) behind a fixed asymmetric zero pad."""
+
+    def __init__(self, cin, cout, k, stride, groups, pad, bias=False):
+        super().__init__(cin, cout, k, stride, 0, groups=groups, bias=bias)
+        self.pad = pad                                  # (begin, end), same for H and W
+
+    def forward(self, x):
+        b, e = self.pad
+        return super().forward(F.pad(x, (b, e, b, e)) if (b or e) else x)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+class MBConv(nn.Module):
+    def __init__(self, cin, cout, k, stride, expand, size, drop_rate):
+        super().__init__()
+        self.cin, self.cout, self.stride, self.expand, self.drop_rate = cin, cout, stride, expand, drop_rate
+        mid = cin * expand
+        if expand != 1:
+            self._expand_conv = nn.Conv2d(cin, mid, 1, bias=False)
+            self._bn0 = nn.BatchNorm2d(mid, eps=1e-3, momentum=0.01)
+        b, e, self.out_size = _static_same_pad(size, k, stride)
+        self._depthwise_conv = _SamePadConv(mid, mid, k, stride, mid, (b, e))
+        self._bn1 = nn.BatchNorm2d(mid, eps=1e-3, momentum=0.01)
+        nsq = max(1, int(cin * 0.25))
+        self._se_reduce = nn.Conv2d(mid, nsq, 1)
+        self._se_expand = nn.Conv2d(nsq, mid, 1)
+        self._project_conv = nn.Conv2d(mid, cout, 1, bias=False)
+        self._bn2 = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01)
+
+    def forward(self, inputs, keep=None):
+        """keep: per-sample {0,1} tensor (N,) for drop-connect in training (None = no drop)."""
+        x = inputs
+        if self.expand != 1:
+            x = _swish(self._bn0(self._expand_conv(x)))
+        x = _swish(self._bn1(self._depthwise_conv(x)))
+        sq = F.adaptive_avg_pool2d(x, 1)
+        sq = self._se_expand(_swish(self._se_reduce(sq)))
+        x = torch.sigmoid(sq) * x
+        x = self._bn2(self._project_conv(x))
+        if self.stride == 1 and self.cin == self.cout:
+            if keep is not None:
+                x = x / (1.0 - self.drop_rate) * keep.view(-1, 1, 1, 1).to(x.dtype)
+            x = x + inputs
+        return x
+
+
+class EfficientNetB4Encoder(nn.Module):
+    """smp EfficientNetEncoder('efficientnet-b4'): features after the stem and after blocks 6, 10, 22, 32."""
+
+    def __init__(self, in_channels: int = 3):
+        super().__init__()
+        b, e, size = _static_same_pad(_EFFB4_IMAGE, 3, 2)
+        self._conv_stem = _SamePadConv(in_channels, 48, 3, 2, 1, (b, e))
+        self._bn0 = nn.BatchNorm2d(48, eps=1e-3, momentum=0.01)
+        blocks = []
+        for rep, k, s, ex, ci, co in _EFFB4_STAGES:
+            for r in range(rep):
+                idx = len(blocks)
+                blk = MBConv(ci if r == 0 else co, co, k, s if r == 0 else 1, ex, size, 0.2 * idx / 32)
+                size = blk.out_size
+                blocks.append(blk)
+        self._blocks = nn.ModuleList(blocks)
+        self.stage_idxs = (6, 10, 22, 32)
+        self.out_channels = (in_channels, 48, 32, 56, 160, 448)
+
+    def forward(self, x, keeps=None):
+        feats = [x]
+        x = _swish(self._bn0(self._conv_stem(x)))
+        feats.append(x)
+        for i, blk in enumerate(self._blocks):
+            x = blk(x, None if keeps is None else keeps[i])
+            if i + 1 in self.stage_idxs:
+                feats.append(x)
+        return feats
+
+
 def _conv2d_relu(cin, cout):
     # smp.base.modules.Conv2dReLU(use_batchnorm=True): Sequential(conv(no bias), bn, relu)
     return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=False))
@@ -231,27 +326,29 @@ class OracleUnet(nn.Module):
                  decoder_attention_type=None, in_channels=3, classes=1, activation=None,
                  aux_params=None):
         super().__init__()
-        if encoder_name not in _RESNET_BLOCKS:
-            raise ValueError(f"oracle supports {list(_RESNET_BLOCKS)}; got {encoder_name}")
+        if encoder_name not in _RESNET_BLOCKS and encoder_name != "efficientnet-b4":
+            raise ValueError(f"oracle supports {list(_RESNET_BLOCKS) + ['efficientnet-b4']}; got {encoder_name}")
         if encoder_depth != 5 or len(decoder_channels) != encoder_depth:
             raise ValueError("decoder_channels length must equal encoder_depth (=5)")
         if encoder_weights is not None or decoder_attention_type is not None \
                 or activation is not None or aux_params is not None or not decoder_use_batchnorm:
             raise ValueError("oracle: unsupported option")
-        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        self.encoder = EfficientNetB4Encoder(in_channels) if encoder_name == "efficientnet-b4" else ResNetEncoder(encoder_name, in_channels)
         self.decoder = self._DECODER(self.encoder.out_channels, tuple(decoder_channels))
         head = nn.Conv2d(decoder_channels[-1], classes, 3, 1, 1)
         nn.init.xavier_uniform_(head.weight)             # smp initialize_head
         nn.init.constant_(head.bias, 0)
         self.segmentation_head = nn.Sequential(head, nn.Identity(), nn.Identity())
 
-    def forward(self, x):
+    def forward(self, x, keeps=None):
+        """keeps: efficientnet only — per-block per-sample drop-connect keep masks (list of (N,) tensors or None)."""
         h, w = x.shape[-2:]
         if h % 32 != 0 or w % 32 != 0:
             raise RuntimeError(
                 f"Wrong input shape height={h}, width={w}. Expected image height and width "
                 f"divisible by 32.")
-        return self.segmentation_head(self.decoder(*self.encoder(x)))
+        feats = self.encoder(x, keeps) if keeps is not None else self.encoder(x)
+        return self.segmentation_head(self.decoder(*feats))
 
 
 class OracleUnetPlusPlus(OracleUnet):
@@ -384,25 +481,42 @@ def conv_flops(encoder_name="resnet34", h=512, w=512, decoder_channels=(256, 128
     macs = []          # (macs, needs_dgrad)
     def conv(cin, cout, k, ho, wo, dgrad=True):
         macs.append((cin * cout * k * k * ho * wo, dgrad))
-    conv(in_channels, 64, 7, h // 2, w // 2, dgrad=False)
-    cin, hh, ww = 64, h // 4, w // 4
-    exp = _RESNET_EXPANSION[encoder_name]
-    for li, (wd, nb) in enumerate(zip(_RESNET_WIDTHS, _RESNET_BLOCKS[encoder_name]), start=1):
-        for b in range(nb):
-            s = 2 if (b == 0 and li > 1) else 1
-            if exp == 1:
-                hh, ww = hh // s, ww // s
-                conv(cin, wd, 3, hh, ww)
-                conv(wd, wd, 3, hh, ww)
-            else:
-                conv(cin, wd, 1, hh, ww)
-                hh, ww = hh // s, ww // s
-                conv(wd, wd, 3, hh, ww)
-                conv(wd, wd * exp, 1, hh, ww)
-            if s != 1 or cin != wd * exp:
-                conv(cin, wd * exp, 1, hh, ww)
-            cin = wd * exp
-    enc = [512 * exp, 256 * exp, 128 * exp, 64 * exp, 64]
+    if encoder_name == "efficientnet-b4":       # dense 1x1 / stem convs, depthwise convs (cin = 1 per group) and the SE FCs
+        hh, ww = h // 2, w // 2
+        conv(in_channels, 48, 3, hh, ww, dgrad=False)
+        for rep, k, st, ex, ci, co in _EFFB4_STAGES:
+            for r in range(rep):
+                bc, bs = (ci, st) if r == 0 else (co, 1)
+                mid = bc * ex
+                if ex != 1:
+                    conv(bc, mid, 1, hh, ww)
+                hh, ww = hh // bs, ww // bs
+                conv(1, mid, k, hh, ww)
+                nsq = max(1, int(bc * 0.25))
+                conv(mid, nsq, 1, 1, 1)
+                conv(nsq, mid, 1, 1, 1)
+                conv(mid, co, 1, hh, ww)
+        enc = [448, 160, 56, 32, 48]
+    else:
+        conv(in_channels, 64, 7, h // 2, w // 2, dgrad=False)
+        cin, hh, ww = 64, h // 4, w // 4
+        exp = _RESNET_EXPANSION[encoder_name]
+        for li, (wd, nb) in enumerate(zip(_RESNET_WIDTHS, _RESNET_BLOCKS[encoder_name]), start=1):
+            for b in range(nb):
+                s = 2 if (b == 0 and li > 1) else 1
+                if exp == 1:
+                    hh, ww = hh // s, ww // s
+                    conv(cin, wd, 3, hh, ww)
+                    conv(wd, wd, 3, hh, ww)
+                else:
+                    conv(cin, wd, 1, hh, ww)
+                    hh, ww = hh // s, ww // s
+                    conv(wd, wd, 3, hh, ww)
+                    conv(wd, wd * exp, 1, hh, ww)
+                if s != 1 or cin != wd * exp:
+                    conv(cin, wd * exp, 1, hh, ww)
+                cin = wd * exp
+        enc = [512 * exp, 256 * exp, 128 * exp, 64 * exp, 64]
     in_ch = [enc[0]] + list(decoder_channels[:-1])
     skip = enc[1:] + [0]
     if arch == "Unet":

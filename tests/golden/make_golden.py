@@ -77,10 +77,14 @@ def kernel_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "effb4":      # add this one fixture without regenerating the others
+        unet_case("unet_effb4_64", "efficientnet-b4", 2, 64, 64, 5, "combo")
+        sys.exit(0)
     unet_case("unet_r18_256", "resnet18", 1, 256, 256, 42, "dice")      # BASELINE config 1
     unet_case("unet_r18_64_combo", "resnet18", 2, 64, 64, 7, "combo")
     unet_case("unet_r34_64", "resnet34", 1, 64, 64, 3, "dice")
     unet_case("unetpp_r18_64_combo", "resnet18", 2, 64, 64, 11, "combo", arch="UnetPlusPlus")
+    unet_case("unet_effb4_64", "efficientnet-b4", 2, 64, 64, 5, "combo")                       # BASELINE config 4 encoder
     kernel_cases()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -49,6 +49,30 @@ def test_state_dict_contract_matches_oracle(U):
         assert all(m.stages[i][1] == m.stages[i + 1][0] for i in range(len(m.stages) - 1))
 
 
+def test_efficientnet_b4_state_dict_contract(U):
+    """EfficientNet-b4 encoder (BASELINE config 4) under both decoders: smp state_dict keys / shapes, parameter count,
+    a loss-free load_state_dict round trip, BatchNorm hyper-parameters of the encoder, torch-default conv init."""
+    from oracle import unet_oracle as O
+    for arch, count in (("Unet", 19_419_289), ("UnetPlusPlus", 20_006_713)):
+        torch.manual_seed(1)
+        m, ref = getattr(U, arch)("efficientnet-b4"), O.build("efficientnet-b4", arch=arch)
+        sd, so = m.state_dict(), ref.state_dict()
+        assert list(sd.keys()) == list(so.keys())
+        assert all(sd[k].shape == so[k].shape and sd[k].dtype == so[k].dtype for k in so)
+        assert m.num_parameters() == count == sum(p.numel() for p in m.parameters())
+        w = sd["encoder._blocks.2._expand_conv.weight"]        # kaiming_uniform(a=sqrt(5)): bound = 1/sqrt(fan_in)
+        assert float(w.abs().max()) <= 1 / 24 ** 0.5 + 1e-6 and float(w.abs().max()) > 0.9 / 24 ** 0.5
+        b = sd["encoder._blocks.2._se_reduce.bias"]
+        assert 0 < float(b.abs().max()) <= 1 / 144 ** 0.5 + 1e-6
+        m.load_state_dict(so)
+        assert all(torch.equal(m.state_dict()[k], so[k]) for k in so)
+        logical = sum(float(v.double().abs().sum()) for k, v in so.items() if v.dtype.is_floating_point and "running" not in k)
+        assert abs(float(m.flat_parameters().double().abs().sum()) - logical) < 1e-6 * logical
+        assert m.stages[0][0] == 0 and m.stages[-1][1] == m.flat_parameters().numel()
+        assert m._n_mb == 32 and m._mb_drop[0] == 0 and abs(m._mb_drop[31] - 0.2 * 31 / 32) < 1e-7
+        assert m._mb_drop[2] == 0                               # block 2 changes stride/width: no identity skip, no drop
+
+
 def test_init_follows_smp_spec(U):
     torch.manual_seed(0)
     m = U.Unet("resnet18")
@@ -63,7 +87,7 @@ def test_init_follows_smp_spec(U):
 
 
 def test_constructor_rejects_unsupported(U):
-    for kw in (dict(encoder_name="efficientnet-b4"), dict(encoder_weights="imagenet"), dict(decoder_attention_type="scse"),
+    for kw in (dict(encoder_name="mobilenet_v2"), dict(encoder_weights="imagenet"), dict(decoder_attention_type="scse"),
                dict(activation="sigmoid"), dict(aux_params={"classes": 2}), dict(decoder_channels=(256, 128, 64)),
                dict(encoder_depth=4, decoder_channels=(256, 128, 64, 32)), dict(decoder_channels=(256, 128, 64, 32, 10))):
         with pytest.raises(ValueError):
@@ -71,7 +95,7 @@ def test_constructor_rejects_unsupported(U):
     with pytest.raises(ValueError, match="Unsupported model"):
         U.create_model("DeepLabV3Plus")
     with pytest.raises(ValueError):
-        U.UnetPlusPlus(encoder_name="efficientnet-b4")
+        U.UnetPlusPlus(encoder_name="timm-regnety_016")
 
 
 def test_config_factories(U):
@@ -167,5 +191,11 @@ def test_workspace_plan_sizes(U):
             assert lib.uwm_workspace_bytes(h, 16, 512, 512, 0) < b16
             gib[(arch, enc)] = b16 / 2 ** 30
             lib.uwm_destroy(h)
+    desc = L.uwm_unet_desc(L.ENC["efficientnet-b4"], 3, 1, (C.c_int * 5)(256, 128, 64, 32, 16), 1e-5, 0.1, 0)
+    h = C.c_void_p()
+    L.check(lib.uwm_create(C.byref(desc), C.byref(h)))
+    b1, b16 = (lib.uwm_workspace_bytes(h, n, 512, 512, 1) for n in (1, 16))
+    assert b16 < 16.5 * b1 and b16 / 2 ** 30 < 40, (b1, b16)    # every MBConv stage materialised (round-1 path)
+    lib.uwm_destroy(h)
     assert 6.5 < gib[("Unet", "resnet34")] < 8.5, gib           # BASELINE config 2: ~7.5 GB of the 288 GB
     assert gib[("UnetPlusPlus", "resnet34")] < 16 and gib[("UnetPlusPlus", "resnet50")] < 30, gib

@@ -583,3 +583,81 @@ def test_device_input_pipeline_matches_reference_transform(cuda):
     assert (x2.cpu() - (img2.permute(0, 3, 1, 2).float() / 255.0 - mean) / std).abs().max() < 1e-5
     with pytest.raises(ValueError):
         U.device_preprocess(img2.to(cuda), flags=torch.tensor([4, 0], dtype=torch.int32))
+
+
+def _effb4_grad_check(model, ref, l2_rel=3e-2, cos_min=0.9995):
+    """_grad_check for the MBConv encoder.  A per-channel shift of a block output has no effect through the next
+    1x1 conv + train-mode BatchNorm, so the `_bn2.bias` gradients are rounding noise around zero in BOTH runs:
+    they are held against the size of the matching `_bn2.weight` gradient instead of their own."""
+    gref = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        g, r = p.grad.detach().cpu().double(), gref[n].grad.double()
+        if n.endswith("_bn2.bias") and "_blocks" in n:
+            scale = gref[n[:-4] + "weight"].grad.double().norm()
+            assert (g - r).norm() <= l2_rel * scale, f"{n}: {(g - r).norm()} vs scale {scale}"
+            continue
+        if r.norm() == 0:
+            assert g.norm() == 0, n
+            continue
+        l2 = ((g - r).norm() / r.norm()).item()
+        cos = ((g.flatten() @ r.flatten()) / (g.norm() * r.norm())).item()
+        assert l2 < l2_rel, f"{n}: relative L2 error {l2}"
+        assert cos > cos_min, f"{n}: cosine {cos}"
+
+
+@pytest.mark.parametrize("arch,n,h,w,drop", [("Unet", 4, 128, 128, False), ("Unet", 4, 128, 160, True), ("UnetPlusPlus", 2, 128, 128, True)])
+def test_efficientnet_b4_encoder_parity(cuda, arch, n, h, w, drop):
+    """Unet / UnetPlusPlus over the EfficientNet-b4 encoder (BASELINE config 4; README.md:173-176): MBConv blocks with
+    static-same-padded depthwise convs, swish, squeeze-and-excitation, BatchNorm(eps 1e-3, momentum 0.01) and
+    drop-connect (same per-block, per-sample keep masks on both sides).  Train forward, loss, every gradient,
+    running statistics, then the eval forward."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    m, ref = _pair("efficientnet-b4", seed=3, dev=cuda, arch=arch)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    x, t = O.synthetic_batch(n, h, w, seed=13)
+    nb = len(ref.encoder._blocks)
+    keep = (torch.rand(nb, n, generator=torch.Generator().manual_seed(1)) > 0.3).float()
+    m.train(); ref.train()
+    m.drop_connect = drop
+    m._keep_override = keep if drop else None
+    crit_ref = O.CombinedLoss([O.BCEWithLogits(), O.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    crit = U.CombinedLoss([U.BCEWithLogitsLoss(), U.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    out_ref = ref(x, [keep[i] for i in range(nb)] if drop else None)
+    loss_ref = crit_ref(out_ref, t.unsqueeze(1)); loss_ref.backward()
+    out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda)); loss.backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    _effb4_grad_check(m, ref)
+    bref = dict(ref.named_buffers())
+    for k, b in m.named_buffers():
+        assert (b.detach().cpu().double() - bref[k].double()).abs().max() < 1e-4, k
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert (m(x.to(cuda)).cpu() - ref(x)).abs().max() < LOGIT_TOL
+
+
+def test_efficientnet_b4_drop_connect_draw_and_trainer(cuda):
+    """The host draws efficientnet_pytorch's drop_connect masks (floor(keep_prob + U) / keep_prob per block and
+    sample); a dropped sample's block reduces to the identity; fused Trainer steps run and the loss falls."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd.train import Trainer
+    from oracle import unet_oracle as O
+    torch.manual_seed(0)
+    m = U.Unet("efficientnet-b4").to(cuda)
+    x, t = O.synthetic_batch(4, 64, 64, seed=2)
+    m.train()
+    m._forward_raw(x.to(cuda), training=True)
+    rs = m._rowscale.cpu()
+    assert rs.shape == (32, 4)
+    for i in range(32):
+        p = m._mb_drop[i]
+        assert all(abs(v) < 1e-6 or abs(v - 1 / (1 - p)) < 1e-5 for v in rs[i].tolist()), (i, rs[i])
+    assert torch.all(rs[0] == 1) and (rs == 0).any()          # block 0 never drops; with p up to 0.19 over 128 draws some do
+    m.eval()
+    m._forward_raw(x.to(cuda), training=False)
+    assert m._rowscale is None
+    tr = Trainer(m, w_dice=0.5, w_bce=0.5, smooth=1e-5, lr=1e-3)
+    losses = [float(tr.step(x.to(cuda), t.to(cuda))[0]) for _ in range(12)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses

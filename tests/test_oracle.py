@@ -61,6 +61,37 @@ def test_resnet50_structure():
     assert m.encoder.out_channels == (3, 64, 256, 512, 1024, 2048)
 
 
+def test_efficientnet_b4_structure():
+    """EfficientNet-b4 encoder restatement (BASELINE config 4): the encoder holds the published efficientnet-b4
+    parameter count minus its classifier head (19,341,616 - conv_head 802,816 - bn1 3,584 - fc 1,793,000), smp's
+    out_channels, feature strides, the static "same" paddings along the 380-pixel chain and the drop-connect ramp."""
+    m = O.build("efficientnet-b4")
+    enc = m.encoder
+    assert sum(p.numel() for p in enc.parameters()) == 19_341_616 - 802_816 - 3_584 - 1_793_000 == 16_742_216
+    assert sum(p.numel() for p in m.parameters()) == 19_419_289
+    assert sum(p.numel() for p in O.build("efficientnet-b4", arch="UnetPlusPlus").parameters()) == 20_006_713
+    assert enc.out_channels == (3, 48, 32, 56, 160, 448) and len(enc._blocks) == 32
+    assert enc._conv_stem.pad == (0, 1)
+    pads = {(b._depthwise_conv.kernel_size[0], b._depthwise_conv.stride[0], b._depthwise_conv.pad) for b in enc._blocks}
+    assert pads == {(3, 1, (1, 1)), (3, 2, (0, 1)), (5, 2, (2, 2)), (5, 2, (1, 2)), (5, 1, (2, 2))}
+    assert abs(enc._blocks[31].drop_rate - 0.2 * 31 / 32) < 1e-12 and enc._blocks[0].drop_rate == 0
+    sd = m.state_dict()
+    assert sd["encoder._blocks.0._depthwise_conv.weight"].shape == (48, 1, 3, 3)
+    assert "encoder._blocks.0._expand_conv.weight" not in sd and sd["encoder._blocks.2._expand_conv.weight"].shape == (144, 24, 1, 1)
+    assert sd["encoder._blocks.2._se_reduce.weight"].shape == (6, 144, 1, 1) and sd["encoder._blocks.2._se_reduce.bias"].shape == (6,)
+    assert sd["decoder.blocks.0.conv1.0.weight"].shape == (256, 448 + 160, 3, 3)
+    assert enc._blocks[2]._bn0.eps == 1e-3 and enc._blocks[2]._bn0.momentum == 0.01
+    x = torch.randn(2, 3, 64, 96)
+    feats = enc(x)
+    assert [tuple(f.shape[1:]) for f in feats] == [(3, 64, 96), (48, 32, 48), (32, 16, 24), (56, 8, 12), (160, 4, 6), (448, 2, 3)]
+    # drop-connect: a dropped sample passes through the block unchanged
+    blk = enc._blocks[1].train()
+    xin = torch.randn(2, 24, 8, 8)
+    out = blk(xin, torch.tensor([0.0, 1.0]))
+    assert torch.equal(out[0], xin[0]) and not torch.equal(out[1], xin[1])
+    assert O.conv_flops("efficientnet-b4", 512, 512) == (36_848_411_328, 110_375_364_672)
+
+
 def test_conv_flops_match_survey():
     assert O.conv_flops("resnet34", 512, 512) == (62_511_906_816, 186_302_595_072)
     assert O.conv_flops("resnet18", 256, 256) == (10_796_138_496, 32_080_134_144)
@@ -106,7 +137,7 @@ def test_metrics_closed_forms():
     assert O.predict_mask(lg, 0.5, apply_sigmoid=True).flatten().tolist() == [255, 255, 0, 255]
 
 
-@pytest.mark.parametrize("name", ["unet_r18_256", "unet_r18_64_combo", "unet_r34_64", "unetpp_r18_64_combo"])
+@pytest.mark.parametrize("name", ["unet_r18_256", "unet_r18_64_combo", "unet_r34_64", "unetpp_r18_64_combo", "unet_effb4_64"])
 def test_oracle_reproduces_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     enc, n, h, w, seed, loss = str(g["encoder"]), int(g["n"]), int(g["h"]), int(g["w"]), int(g["seed"]), str(g["loss"])
@@ -125,7 +156,10 @@ def test_oracle_reproduces_golden(name):
     l = dice if loss == "dice" else 0.5 * bce + 0.5 * dice
     l.backward()
     gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
-    assert np.allclose(gn, g["grad_norm"], rtol=3e-2, atol=1e-7)
+    # (a per-channel shift ahead of a 1x1 conv + BatchNorm has no effect: EfficientNet's _bn2.bias gradients are pure
+    # rounding noise, not comparable between two runs)
+    live = np.array([not k.endswith("_bn2.bias") for k, _ in model.named_parameters()])
+    assert np.allclose(gn[live], g["grad_norm"][live], rtol=3e-2, atol=1e-7)
     assert [k for k, _ in model.named_parameters()] == list(g["param_names"])
 
 

@@ -18,7 +18,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "mbconv.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
 
 
@@ -39,7 +39,7 @@ class uwm_src(C.Structure):
 
 KIND_CONV_W, KIND_BIAS, KIND_BN_GAMMA, KIND_BN_BETA, KIND_BN_MEAN, KIND_BN_VAR = range(6)
 ARENA_PARAM, ARENA_BUFFER = 0, 1
-ENC = {"resnet18": 18, "resnet34": 34, "resnet50": 50}
+ENC = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "efficientnet-b4": 104}
 ARCH = {"Unet": 0, "UnetPlusPlus": 1}
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
@@ -69,6 +69,9 @@ SIGNATURES = {
     "uwm_scale": (I, [P, L, F, P]),
     "uwm_set_winograd": (I, [I]),
     "uwm_set_join_stream": (I, [P, P]),
+    "uwm_set_drop_connect": (I, [P, P]),
+    "uwm_num_mbconv_blocks": (I, [P]),
+    "uwm_mbconv_drop_rate": (F, [P, I]),
     "uwm_preprocess_u8": (I, [P, I, I, I, I, C.POINTER(C.c_float), C.POINTER(C.c_float), P, P, P]),
     "uwm_preprocess_mask_u8": (I, [P, I, I, I, I, P, P, P]),
     "uwm_resize_threshold": (I, [P, I, I, I, I, I, I, F, I, P, P, P]),

@@ -206,9 +206,8 @@ hipError_t launch_maxpool_bwd(const float* gout, const uint8_t* idx, const float
 // per-channel  dbeta = sum g,  dgamma = sum g * (y-mean)*rstd   (fp32 per thread, fp64 across)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            double* dgamma, double* dbeta, size_t npix, int C) {
-  __shared__ float red[256 * 8];
-  const int CW = C > 1024 ? 1024 : C;         // channels per blockIdx.y slice (wide layers: resnet50's 2048)
+                                                            double* dgamma, double* dbeta, size_t npix, int C, int CW) {
+  __shared__ float red[256 * 8];               // CW = channels per blockIdx.y slice (wide layers: resnet50's 2048)
   const int c0 = blockIdx.y * CW;
   const int tc = CW / 4;                      // threads along channels (<= 256)
   const int tr = 256 / tc;                    // pixel rows per pass
@@ -247,11 +246,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mean, const float* rstd, double* dgamma,
                                 double* dbeta, size_t npix, int C, hipStream_t st) {
-  const int CW = C > 1024 ? 1024 : C;
-  if ((C & 3) || (C % CW) || CW / 4 > 256) return hipErrorInvalidValue;     // any channel count that is a multiple of 4: idle tail threads
+  int CW = 0;                                  // widest slice <= 1024 channels that divides C (1632 -> 816, 2688 -> 896)
+  for (int d = 1; d <= C && !CW; ++d) if (C % d == 0 && C / d <= 1024 && (C / d) % 4 == 0) CW = C / d;
+  if (!CW) return hipErrorInvalidValue;     // any channel count that is a multiple of 4: idle tail threads
   const int tr = 256 / (CW / 4);
   unsigned nb = nblocks(npix, tr * 8);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CW), dim3(256), 0, st, g, y, mean, rstd, dgamma, dbeta, npix, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, C / CW), dim3(256), 0, st, g, y, mean, rstd, dgamma, dbeta, npix, C, CW);
   return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ struct BNL {
   int nrep;                        // statistics copies (power of 2): spreads the conv epilogues' fp64 atomics
   size_t dcount() const { return 2 * (size_t)C + (size_t)nrep * 2 * C; }
   size_t f_off;                    // workspace floats: mean, rstd, scale, shift (4*C)
+  float eps = 0.f, mom = 0.f;      // 0 = the descriptor's bn_eps / bn_momentum (EfficientNet encoder layers carry their own)
 };
 struct ConvL {
   std::string name; int Cin, CinP, Cout, CoutP, k, stride, pad, Kpad, KpadD, stage;
@@ -53,6 +54,9 @@ struct DecL { int c1, c2, C0, C1; };
 // UnetPlusPlus decoder block.  Tensor ids: 0..4 = encoder features f1..f5 (f1 = stem, f5 = deepest), 5 + i = output
 // of node i.  lvl = log2 of the down-scale of the node's OUTPUT (f1: 1 ... f5: 5, final node: 0).
 struct NodeL { int c1, c2, prev; std::vector<int> skips; int C0, C1, lvl; };
+// EfficientNet MBConv block: [expand 1x1 -> BN -> swish] -> depthwise k x k (static same pad) -> BN -> swish -> SE ->
+// project 1x1 -> BN [-> drop-connect + identity].  ce = -1 when expand_ratio == 1.
+struct MBL { int ce = -1, cdw = -1, cr = -1, cx = -1, cp = -1, Cin = 0, Cout = 0, mid = 0, nsq = 0, k = 3, stride = 1, pb = 0; bool skip = false; float drop = 0.f; };
 
 struct Plan {                       // workspace layout for one (N,H,W,training)
   int N = 0, H = 0, W = 0, training = -1;
@@ -63,6 +67,10 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   bool wino_ok(size_t ci) const { return winograd_enabled() && oh[ci] >= 8 && ow[ci] >= 16; }   // conv_wino tile fits
   std::vector<size_t> xn, gx;       // per encoder block: residual output / its gradient
   std::vector<size_t> dcat, gskip;  // per decoder block (UnetPlusPlus: dcat[0] = shared scratch, gskip[0..3] = f4,f3,f2,f1 accumulators)
+  size_t stem_a = 0;                // EfficientNet: materialised stem feature f1 = swish(bn(conv_stem))
+  std::vector<size_t> a0, a1, a2, se;   // EfficientNet per block: swish(bn0(expand)), swish(bn1(dw)), SE-scaled, {pool[N][mid], s[N][mid], hpre[N][nsqP]}
+  std::vector<int> mh, mw;          // EfficientNet per block: output height / width
+  size_t se_g = 0;                  // EfficientNet: SE backward scratch {gs[N][maxmid], gpool[N][maxmid]}
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
@@ -76,6 +84,11 @@ struct uwm_model {
   std::vector<DecL> dec;
   std::vector<NodeL> nodes;          // UnetPlusPlus (arch 1) decoder in forward order; empty for Unet
   int featC[4] = {64, 128, 256, 512};  // channels of the encoder features f2..f5
+  int f1C = 64;                      // channels of f1 (stem feature)
+  std::vector<MBL> mb;               // EfficientNet encoder blocks (empty for ResNets)
+  int feat_blk[4] = {0, 0, 0, 0};    // EfficientNet: index of the block whose output is f2..f5
+  const float* keep = nullptr;       // uwm_set_drop_connect: device [mb.size()][N] row scales, or nullptr
+  const float* keep_fwd = nullptr;   // the pointer the last training forward used (the backward must use the same)
   int stem = -1, head = -1, CP = 4, CinP = 4;
   long long param_floats = 0, buffer_floats = 0, param_count = 0;
   long long stage_begin[6] = {0, 0, 0, 0, 0, 0};
@@ -94,18 +107,18 @@ struct uwm_model {
   int pack_mode = -1;                 // uwm_set_winograd mode those repacks were made for
 };
 
-static int add_bn(uwm_model* m, const std::string& name, int C, int stage) {
-  BNL b; b.name = name; b.C = C; b.stage = stage; b.nrep = C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); b.g_off = b.b_off = b.rm_off = b.rv_off = -1; b.d_off = b.f_off = 0;
+static int add_bn(uwm_model* m, const std::string& name, int C, int stage, float eps = 0.f, float mom = 0.f) {
+  BNL b; b.eps = eps; b.mom = mom; b.name = name; b.C = C; b.stage = stage; b.nrep = C <= 64 ? 32 : (C <= 128 ? 16 : (C <= 256 ? 8 : 4)); b.g_off = b.b_off = b.rm_off = b.rv_off = -1; b.d_off = b.f_off = 0;
   m->bns.push_back(b); return (int)m->bns.size() - 1;
 }
 static int add_conv(uwm_model* m, const std::string& name, int Cin, int Cout, int k, int stride, int pad, int stage,
-                    bool dgrad, const std::string& bn_name, bool bias = false) {
+                    bool dgrad, const std::string& bn_name, bool bias = false, float bn_eps = 0.f, float bn_mom = 0.f) {
   ConvL c; c.name = name; c.Cin = Cin; c.CinP = (int)rup(Cin, 4); c.Cout = Cout; c.CoutP = (int)rup(Cout, 4);
   c.k = k; c.stride = stride; c.pad = pad; c.stage = stage; c.dgrad = dgrad;
   c.Kpad = (int)rup((long long)k * k * c.CinP, 32);
   c.KpadD = (int)rup((long long)k * k * c.CoutP, 32);
   c.w_off = -1; c.bias_off = bias ? 0 : -1; c.wd_off = 0; c.wu_off = c.wud_off = 0;
-  c.bn = bn_name.empty() ? -1 : add_bn(m, bn_name, Cout, stage);
+  c.bn = bn_name.empty() ? -1 : add_bn(m, bn_name, Cout, stage, bn_eps, bn_mom);
   m->convs.push_back(c); return (int)m->convs.size() - 1;
 }
 
@@ -120,44 +133,81 @@ static void push_info(uwm_model* m, const std::string& name, int kind, int arena
 
 static int build_model(uwm_model* m) {
   const uwm_unet_desc& d = m->desc;
-  int nb[4]; int expn = 1;
+  int nb[4] = {0, 0, 0, 0}; int expn = 1;
+  const bool effnet = d.encoder == UWM_ENC_EFFICIENTNET_B4;
   if (d.encoder == UWM_ENC_RESNET18) { nb[0] = 2; nb[1] = 2; nb[2] = 2; nb[3] = 2; }
   else if (d.encoder == UWM_ENC_RESNET34) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; }
   else if (d.encoder == UWM_ENC_RESNET50) { nb[0] = 3; nb[1] = 4; nb[2] = 6; nb[3] = 3; expn = 4; }
-  else return fail("unsupported encoder %d (supported: resnet18, resnet34, resnet50)", d.encoder);
+  else if (!effnet) return fail("unsupported encoder %d (supported: resnet18, resnet34, resnet50, efficientnet-b4)", d.encoder);
   if (d.in_channels < 1 || d.in_channels > 4) return fail("in_channels must be 1..4, got %d", d.in_channels);
   if (d.classes < 1 || d.classes > 4) return fail("classes must be 1..4, got %d", d.classes);
   for (int i = 0; i < 5; ++i)
     if (d.decoder_channels[i] < 4 || (d.decoder_channels[i] & 3)) return fail("decoder_channels[%d]=%d must be a positive multiple of 4", i, d.decoder_channels[i]);
   m->CP = (int)rup(d.classes, 4); m->CinP = (int)rup(d.in_channels, 4);
   const int widths[4] = {64, 128, 256, 512};
-  // backward stages: 0 head+decoder, 1 layer4, 2 layer3, 3 layer2, 4 layer1+stem
-  m->stem = add_conv(m, "encoder.conv1", d.in_channels, 64, 7, 2, 3, 4, false, "encoder.bn1");
-  int cin = 64;
   m->stages.resize(4);
-  for (int s = 0; s < 4; ++s) {
-    const int stage = 4 - s;
-    for (int b = 0; b < nb[s]; ++b) {
-      const int stride = (b == 0 && s > 0) ? 2 : 1;
-      char pre[64]; snprintf(pre, sizeof(pre), "encoder.layer%d.%d", s + 1, b);
-      const std::string P(pre);
-      BlockL bl; bl.stride = stride; bl.Cin = cin; bl.Cout = widths[s] * expn;
-      if (expn == 1) {
-        bl.c1 = add_conv(m, P + ".conv1", cin, widths[s], 3, stride, 1, stage, true, P + ".bn1");
-        bl.c2 = add_conv(m, P + ".conv2", widths[s], widths[s], 3, 1, 1, stage, true, P + ".bn2");
-      } else {            // torchvision Bottleneck v1.5: the stride sits on the 3x3
-        bl.c1 = add_conv(m, P + ".conv1", cin, widths[s], 1, 1, 0, stage, true, P + ".bn1");
-        bl.c2 = add_conv(m, P + ".conv2", widths[s], widths[s], 3, stride, 1, stage, true, P + ".bn2");
-        bl.c3 = add_conv(m, P + ".conv3", widths[s], bl.Cout, 1, 1, 0, stage, true, P + ".bn3");
+  int encc[5] = {512 * expn, 256 * expn, 128 * expn, 64 * expn, 64};
+  // backward stages: 0 head+decoder, 1 layer4, 2 layer3, 3 layer2, 4 layer1+stem
+  if (!effnet) {
+    m->stem = add_conv(m, "encoder.conv1", d.in_channels, 64, 7, 2, 3, 4, false, "encoder.bn1");
+    int cin = 64;
+    for (int s = 0; s < 4; ++s) {
+      const int stage = 4 - s;
+      for (int b = 0; b < nb[s]; ++b) {
+        const int stride = (b == 0 && s > 0) ? 2 : 1;
+        char pre[64]; snprintf(pre, sizeof(pre), "encoder.layer%d.%d", s + 1, b);
+        const std::string P(pre);
+        BlockL bl; bl.stride = stride; bl.Cin = cin; bl.Cout = widths[s] * expn;
+        if (expn == 1) {
+          bl.c1 = add_conv(m, P + ".conv1", cin, widths[s], 3, stride, 1, stage, true, P + ".bn1");
+          bl.c2 = add_conv(m, P + ".conv2", widths[s], widths[s], 3, 1, 1, stage, true, P + ".bn2");
+        } else {            // torchvision Bottleneck v1.5: the stride sits on the 3x3
+          bl.c1 = add_conv(m, P + ".conv1", cin, widths[s], 1, 1, 0, stage, true, P + ".bn1");
+          bl.c2 = add_conv(m, P + ".conv2", widths[s], widths[s], 3, stride, 1, stage, true, P + ".bn2");
+          bl.c3 = add_conv(m, P + ".conv3", widths[s], bl.Cout, 1, 1, 0, stage, true, P + ".bn3");
+        }
+        bl.cd = -1;
+        if (stride != 1 || cin != bl.Cout)
+          bl.cd = add_conv(m, P + ".downsample.0", cin, bl.Cout, 1, stride, 0, stage, true, P + ".downsample.1");
+        m->stages[s].push_back(bl);
+        cin = bl.Cout;
       }
-      bl.cd = -1;
-      if (stride != 1 || cin != bl.Cout)
-        bl.cd = add_conv(m, P + ".downsample.0", cin, bl.Cout, 1, stride, 0, stage, true, P + ".downsample.1");
-      m->stages[s].push_back(bl);
-      cin = bl.Cout;
     }
+  } else {
+    // efficientnet_pytorch "efficientnet-b4" as smp wraps it: width 1.4 / depth 1.8 scaling of the b0
+    // stage table; BatchNorm eps 1e-3, momentum 0.01; Conv2dStaticSamePadding pads computed along the 380-pixel size chain
+    // (asymmetric: begin = total / 2); SE ratio 0.25 of the block INPUT channels; drop-connect 0.2 * idx / 32.
+    struct St { int rep, k, stride, expand, cin, cout; };
+    const St stg[7] = {{2, 3, 1, 1, 48, 24}, {4, 3, 2, 6, 24, 32}, {4, 5, 2, 6, 32, 56}, {6, 3, 2, 6, 56, 112},
+                       {6, 5, 1, 6, 112, 160}, {8, 5, 2, 6, 160, 272}, {2, 3, 1, 6, 272, 448}};
+    const float be = 1e-3f, bm = 0.01f;
+    auto same_pad = [](int size, int k, int st, int* out) { const int o = (size + st - 1) / st; int t = (o - 1) * st + k - size; if (t < 0) t = 0; *out = o; return t / 2; };
+    int size = 380, osz = 0;
+    const int spb = same_pad(size, 3, 2, &osz); size = osz;
+    m->stem = add_conv(m, "encoder._conv_stem", d.in_channels, 48, 3, 2, spb, 4, false, "encoder._bn0", false, be, bm);
+    const int feat_after[4] = {6, 10, 22, 32};             // smp: features after blocks[:6], [:10], [:22], [:32]
+    int idx = 0;
+    for (int sg = 0; sg < 7; ++sg)
+      for (int r = 0; r < stg[sg].rep; ++r, ++idx) {
+        MBL b; b.Cin = r == 0 ? stg[sg].cin : stg[sg].cout; b.Cout = stg[sg].cout; b.k = stg[sg].k;
+        b.stride = r == 0 ? stg[sg].stride : 1; b.mid = b.Cin * stg[sg].expand; b.nsq = std::max(1, b.Cin / 4);
+        b.skip = b.stride == 1 && b.Cin == b.Cout; b.drop = 0.2f * (float)idx / 32.f;
+        int fs = 0; while (idx >= feat_after[fs]) ++fs;     // feature stage this block belongs to (0..3)
+        const int stage = 4 - fs;
+        char pre[64]; snprintf(pre, sizeof(pre), "encoder._blocks.%d", idx);
+        const std::string P(pre);
+        if (stg[sg].expand != 1) b.ce = add_conv(m, P + "._expand_conv", b.Cin, b.mid, 1, 1, 0, stage, true, P + "._bn0", false, be, bm);
+        b.pb = same_pad(size, b.k, b.stride, &osz); size = osz;
+        b.cdw = add_conv(m, P + "._depthwise_conv", 1, b.mid, b.k, b.stride, b.pb, stage, false, P + "._bn1", false, be, bm);
+        b.cr = add_conv(m, P + "._se_reduce", b.mid, b.nsq, 1, 1, 0, stage, false, "", true);
+        b.cx = add_conv(m, P + "._se_expand", b.nsq, b.mid, 1, 1, 0, stage, false, "", true);
+        b.cp = add_conv(m, P + "._project_conv", b.mid, b.Cout, 1, 1, 0, stage, true, P + "._bn2", false, be, bm);
+        m->mb.push_back(b);
+        if (idx + 1 == feat_after[fs]) m->feat_blk[fs] = idx;
+      }
+    encc[0] = 448; encc[1] = 160; encc[2] = 56; encc[3] = 32; encc[4] = 48;
   }
-  const int encc[5] = {512 * expn, 256 * expn, 128 * expn, 64 * expn, 64};
+  m->f1C = encc[4];
   for (int j = 0; j < 4; ++j) m->featC[j] = encc[3 - j];            // f2..f5
   int prev = encc[0];
   if (d.arch == UWM_ARCH_UNET) {
@@ -277,28 +327,48 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   p.loss_scr = alloc(64);
   p.x4 = alloc((size_t)N * H * W * m->CinP);
   int h = H / 2, w = W / 2;
-  p.y[m->stem] = alloc((size_t)N * h * w * 64); p.oh[m->stem] = h; p.ow[m->stem] = w;
-  h /= 2; w /= 2;
-  p.pool = alloc((size_t)N * h * w * 64);
-  p.pool_idx = alloc((size_t)N * h * w * 64 / 4 + 64);
-  size_t nblk = 0; for (auto& s : m->stages) nblk += s.size();
+  const int stemC = m->convs[m->stem].CoutP;
+  p.y[m->stem] = alloc((size_t)N * h * w * stemC); p.oh[m->stem] = h; p.ow[m->stem] = w;
+  size_t nblk = m->mb.size(); for (auto& s : m->stages) nblk += s.size();
   p.xn.assign(nblk, 0); p.gx.assign(nblk, 0);
-  size_t bi = 0; size_t max_in = (size_t)N * h * w * 64;
-  std::vector<int> sh(4), sw(4);
-  for (int s = 0; s < 4; ++s) {
-    for (auto& bl : m->stages[s]) {
-      const int hi = h, wi = w;
-      h /= bl.stride; w /= bl.stride;
-      auto place = [&](int ci, int oh, int ow) { p.y[ci] = alloc((size_t)N * oh * ow * m->convs[ci].Cout); p.oh[ci] = oh; p.ow[ci] = ow; };
-      if (bl.c3 < 0) { place(bl.c1, h, w); place(bl.c2, h, w); }
-      else { place(bl.c1, hi, wi); place(bl.c2, h, w); place(bl.c3, h, w); }
-      if (bl.cd >= 0) place(bl.cd, h, w);
-      const size_t sz = (size_t)N * h * w * bl.Cout;
-      p.xn[bi++] = alloc(sz);
-      if (sz > max_in) max_in = sz;
-      if ((size_t)N * hi * wi * bl.Cin > max_in) max_in = (size_t)N * hi * wi * bl.Cin;
+  size_t bi = 0; size_t max_in = 0, max_mid = 0;
+  auto place = [&](int ci, int oh, int ow) { p.y[ci] = alloc((size_t)N * oh * ow * m->convs[ci].CoutP); p.oh[ci] = oh; p.ow[ci] = ow; };
+  if (m->mb.empty()) {
+    h /= 2; w /= 2;
+    p.pool = alloc((size_t)N * h * w * 64);
+    p.pool_idx = alloc((size_t)N * h * w * 64 / 4 + 64);
+    max_in = (size_t)N * h * w * 64;
+    for (int s = 0; s < 4; ++s) {
+      for (auto& bl : m->stages[s]) {
+        const int hi = h, wi = w;
+        h /= bl.stride; w /= bl.stride;
+        if (bl.c3 < 0) { place(bl.c1, h, w); place(bl.c2, h, w); }
+        else { place(bl.c1, hi, wi); place(bl.c2, h, w); place(bl.c3, h, w); }
+        if (bl.cd >= 0) place(bl.cd, h, w);
+        const size_t sz = (size_t)N * h * w * bl.Cout;
+        p.xn[bi++] = alloc(sz);
+        if (sz > max_in) max_in = sz;
+        if ((size_t)N * hi * wi * bl.Cin > max_in) max_in = (size_t)N * hi * wi * bl.Cin;
+      }
     }
-    sh[s] = h; sw[s] = w;
+  } else {
+    p.stem_a = alloc((size_t)N * h * w * stemC);
+    const size_t nb = m->mb.size();
+    p.a0.assign(nb, 0); p.a1.assign(nb, 0); p.a2.assign(nb, 0); p.se.assign(nb, 0); p.mh.assign(nb, 0); p.mw.assign(nb, 0);
+    for (; bi < nb; ++bi) {
+      const MBL& b = m->mb[bi];
+      const int hi = h, wi = w;
+      h /= b.stride; w /= b.stride;
+      if (b.ce >= 0) { place(b.ce, hi, wi); p.a0[bi] = alloc((size_t)N * hi * wi * b.mid); }
+      place(b.cdw, h, w);
+      p.a1[bi] = alloc((size_t)N * h * w * b.mid); p.a2[bi] = alloc((size_t)N * h * w * b.mid);
+      p.se[bi] = alloc((size_t)N * (2 * b.mid + (size_t)rup(b.nsq, 4)));
+      place(b.cp, h, w);
+      p.oh[b.cr] = p.ow[b.cr] = p.oh[b.cx] = p.ow[b.cx] = 1;
+      p.xn[bi] = alloc((size_t)N * h * w * b.Cout);
+      p.mh[bi] = h; p.mw[bi] = w;
+      max_mid = std::max(max_mid, (size_t)b.mid);
+    }
   }
   for (size_t i = 0; i < m->dec.size(); ++i) {
     h *= 2; w *= 2;
@@ -322,18 +392,28 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   if (training) {
     // gradient buffers (same shapes as their activations)
     h = H / 2; w = W / 2;
-    p.g[m->stem] = alloc((size_t)N * h * w * 64);
-    h /= 2; w /= 2;
-    p.g_pool = alloc((size_t)N * h * w * 64);
-    bi = 0;
-    for (int s = 0; s < 4; ++s)
-      for (auto& bl : m->stages[s]) {
-        for (int ci : {bl.c1, bl.c2, bl.c3, bl.cd})
-          if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].Cout);
-        p.gx[bi++] = alloc((size_t)N * p.oh[bl.c2] * p.ow[bl.c2] * bl.Cout);
+    p.g[m->stem] = alloc((size_t)N * h * w * stemC);
+    if (m->mb.empty()) {
+      h /= 2; w /= 2;
+      p.g_pool = alloc((size_t)N * h * w * 64);
+      bi = 0;
+      for (int s = 0; s < 4; ++s)
+        for (auto& bl : m->stages[s]) {
+          for (int ci : {bl.c1, bl.c2, bl.c3, bl.cd})
+            if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].Cout);
+          p.gx[bi++] = alloc((size_t)N * p.oh[bl.c2] * p.ow[bl.c2] * bl.Cout);
+        }
+      p.tmp = alloc(max_in);
+    } else {
+      for (size_t i = 0; i < m->mb.size(); ++i) {
+        const MBL& b = m->mb[i];
+        for (int ci : {b.ce, b.cdw, b.cp})
+          if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].CoutP);
+        p.gx[i] = alloc((size_t)N * p.mh[i] * p.mw[i] * b.Cout);
       }
+      p.se_g = alloc(2 * (size_t)N * max_mid);
+    }
     h = H / 32; w = W / 32;                       // deepest feature: the decoder loop below doubles from here
-    p.tmp = alloc(max_in);
     p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
     for (size_t i = 0; i < m->dec.size(); ++i) {
       h *= 2; w *= 2;
@@ -350,7 +430,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       }
       p.dcat.assign(1, alloc(max_dcat));
       p.gcat = alloc(max_gcat);
-      const int fc[4] = {m->featC[2], m->featC[1], m->featC[0], 64};       // gradient accumulators of f4, f3, f2, f1
+      const int fc[4] = {m->featC[2], m->featC[1], m->featC[0], m->f1C};       // gradient accumulators of f4, f3, f2, f1
       p.gskip.assign(4, 0);
       for (int j = 0; j < 4; ++j) p.gskip[j] = alloc((size_t)N * (H >> (4 - j)) * (W >> (4 - j)) * fc[j]);
     }
@@ -440,12 +520,13 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
 static hipError_t run_bn_finalize(const Ctx& c, int bi, size_t count, int training) {
   uwm_model* m = c.m; const BNL& b = m->bns[bi];
   float* f = c.F(b.f_off);
+  const float eps = b.eps > 0.f ? b.eps : m->desc.bn_eps, mom = b.mom > 0.f ? b.mom : m->desc.bn_momentum;
   if (training)
     return launch_bn_finalize(c.D(b.d_off) + 2 * b.C, c.D(b.d_off) + 3 * b.C, m->params + b.g_off, m->params + b.b_off,
                               m->buffers + b.rm_off, m->buffers + b.rv_off, f, f + b.C, f + 2 * b.C, f + 3 * b.C, b.C,
-                              (double)count, m->desc.bn_eps, m->desc.bn_momentum, 1, c.st, b.nrep, 2 * b.C);
+                              (double)count, eps, mom, 1, c.st, b.nrep, 2 * b.C);
   return launch_bn_eval(m->params + b.g_off, m->params + b.b_off, m->buffers + b.rm_off, m->buffers + b.rv_off,
-                        f + 2 * b.C, f + 3 * b.C, b.C, m->desc.bn_eps, c.st);
+                        f + 2 * b.C, f + 3 * b.C, b.C, eps, c.st);
 }
 
 // g (masked grad wrt BN output) -> dy ; also writes gamma/beta gradients
@@ -518,10 +599,11 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
   if (conv_bn(m->stem, x4, nullptr, h, w)) return 1;
   Src f1 = lazy_src(c, m->stem, h, w);
   const int h1 = h, w1 = w;
+  Src feats[4];
+  if (m->mb.empty()) {
   h /= 2; w /= 2;
   LCHK(launch_maxpool_fwd(f1, c.F(p.pool), training ? (uint8_t*)c.F(p.pool_idx) : nullptr, N, h, w, st));
   Src cur = mk_src(c.F(p.pool), 64, h, w);
-  Src feats[4];
   size_t bi = 0;
   for (int s = 0; s < 4; ++s) {
     for (auto& bl : m->stages[s]) {
@@ -552,6 +634,53 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
       ++bi;
     }
     feats[s] = cur;
+  }
+  } else {
+    // ---- EfficientNet encoder: every stage of an MBConv block materialised (round-1 correctness-first path)
+    auto bn_ss = [&](int ci, const float** sc, const float** sh_) { const BNL& b = m->bns[m->convs[ci].bn]; *sc = c.F(b.f_off) + 2 * b.C; *sh_ = c.F(b.f_off) + 3 * b.C; };
+    const float *sc, *sf;
+    bn_ss(m->stem, &sc, &sf);
+    LCHK(launch_swish_fwd(c.F(p.y[m->stem]), sc, sf, m->f1C, c.F(p.stem_a), (size_t)N * h * w, st));
+    f1 = mk_src(c.F(p.stem_a), m->f1C, h, w);
+    m->keep_fwd = training ? m->keep : nullptr;
+    Src cur = f1;
+    for (size_t bi = 0; bi < m->mb.size(); ++bi) {
+      const MBL& b = m->mb[bi];
+      const int ho = h / b.stride, wo = w / b.stride;
+      if (ho != p.mh[bi] || wo != p.mw[bi]) return fail("internal: MBConv block %d plan mismatch", (int)bi);
+      const float* dwin = cur.ptr;
+      if (b.ce >= 0) {
+        if (conv_bn(b.ce, cur, nullptr, h, w)) return 1;
+        bn_ss(b.ce, &sc, &sf);
+        LCHK(launch_swish_fwd(c.F(p.y[b.ce]), sc, sf, b.mid, c.F(p.a0[bi]), (size_t)N * h * w, st));
+        dwin = c.F(p.a0[bi]);
+      }
+      const ConvL& dw = m->convs[b.cdw];
+      const size_t npo = (size_t)N * ho * wo;
+      LCHK(launch_dw_fwd(dwin, m->params + dw.w_off, dw.Kpad, b.k, b.stride, b.pb, N, h, w, b.mid, ho, wo, c.F(p.y[b.cdw]), st));
+      if (training) {
+        const BNL& b1 = m->bns[dw.bn];
+        LCHK(launch_colstats(c.F(p.y[b.cdw]), npo, b.mid, c.D(b1.d_off) + 2 * b1.C, c.D(b1.d_off) + 3 * b1.C, st));
+        LCHK(run_bn_finalize(c, dw.bn, npo, 1));
+      }
+      bn_ss(b.cdw, &sc, &sf);
+      LCHK(launch_swish_fwd(c.F(p.y[b.cdw]), sc, sf, b.mid, c.F(p.a1[bi]), npo, st));
+      float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
+      HIPCHK(hipMemsetAsync(pool, 0, (size_t)N * b.mid * sizeof(float), st));
+      LCHK(launch_se_reduce_hw(c.F(p.a1[bi]), nullptr, N, (size_t)ho * wo, b.mid, (float)(1.0 / ((double)ho * wo)), pool, st));
+      const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
+      LCHK(launch_se_fc_fwd(pool, m->params + cr.w_off, m->params + cr.bias_off, cr.Kpad, m->params + cx.w_off,
+                            m->params + cx.bias_off, cx.Kpad, N, b.mid, b.nsq, hpre, sv, st));
+      LCHK(launch_se_scale(c.F(p.a1[bi]), sv, N, (size_t)ho * wo, b.mid, c.F(p.a2[bi]), st));
+      Src a2 = mk_src(c.F(p.a2[bi]), b.mid, ho, wo);
+      if (conv_bn(b.cp, a2, nullptr, ho, wo)) return 1;
+      bn_ss(b.cp, &sc, &sf);
+      const float* rs = (b.skip && b.drop > 0.f && m->keep_fwd) ? m->keep_fwd + bi * (size_t)N : nullptr;
+      LCHK(launch_mb_out(c.F(p.y[b.cp]), sc, sf, rs, b.skip ? cur.ptr : nullptr, N, (size_t)ho * wo, b.Cout, c.F(p.xn[bi]), st));
+      h = ho; w = wo;
+      cur = mk_src(c.F(p.xn[bi]), b.Cout, h, w);
+      for (int fs = 0; fs < 4; ++fs) if ((int)bi == m->feat_blk[fs]) feats[fs] = cur;
+    }
   }
   Src d = feats[3];
   for (size_t i = 0; i < m->dec.size(); ++i) {
@@ -615,11 +744,14 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
   int sh[4], sw[4];
   { int h = H / 4, w = W / 4; for (int s = 0; s < 4; ++s) { if (s > 0) { h /= 2; w /= 2; } sh[s] = h; sw[s] = w; } }
   std::vector<size_t> first_blk(4); { size_t b = 0; for (int s = 0; s < 4; ++s) { first_blk[s] = b; b += m->stages[s].size(); } }
+  const bool effnet = !m->mb.empty();
+  auto feat_blk = [&](int s) -> size_t { return effnet ? (size_t)m->feat_blk[s] : first_blk[s] + m->stages[s].size() - 1; };
   auto feat_src = [&](int s) {      // materialised output of encoder stage s (f2..f5)
-    const size_t lb = first_blk[s] + m->stages[s].size() - 1;
-    return mk_src(c.F(p.xn[lb]), m->stages[s].back().Cout, sh[s], sw[s]);
+    return mk_src(c.F(p.xn[feat_blk(s)]), m->featC[s], sh[s], sw[s]);
   };
-  Src f1 = lazy_src(c, m->stem, h1, w1);
+  // ResNet features are ReLU outputs (the consumer's gradient is masked by feature > 0); EfficientNet's are linear
+  auto feat_mask = [&](const Src& f) -> const float* { return effnet ? nullptr : f.ptr; };
+  Src f1 = effnet ? mk_src(c.F(p.stem_a), m->f1C, h1, w1) : lazy_src(c, m->stem, h1, w1);
 
   if (sb <= 0 && se > 0) {
     HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
@@ -660,17 +792,18 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       Src skip; const Src* sp = nullptr;
       if (i < 3) { skip = feat_src(2 - i); sp = &skip; } else if (i == 3) { skip = f1; sp = &skip; }
       LCHK(run_wgrad(c, dl.c1, prev, sp, c.F(p.g[dl.c1]), h, w));
-      float* gprev = (i == 0) ? c.F(p.gx[first_blk[3] + m->stages[3].size() - 1]) : c.F(p.g[m->dec[i - 1].c2]);
+      float* gprev = (i == 0) ? c.F(p.gx[feat_blk(3)]) : c.F(p.g[m->dec[i - 1].c2]);
+      const float* pm = (i == 0) ? feat_mask(prev) : prev.ptr;
       const ConvL& c1v = m->convs[dl.c1];
       if (c1v.wud_off && p.wino_ok((size_t)dl.c1) && !(h & 1) && !(w & 1)) {
         // Winograd dgrad writes the 2x2-pooled, ReLU-masked gradient of up(prev) and the skip gradient directly:
         // the full-resolution dcat buffer and the upsplit pass never exist
-        UpSplit us{gprev, dl.C0, prev.ptr, prev.scale, prev.shift, 0};
+        UpSplit us{gprev, dl.C0, pm, prev.scale, prev.shift, 0};
         LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, nullptr, nullptr, nullptr,
                        nullptr, &us));
       } else {
         LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, c.F(p.dcat[i]), nullptr, nullptr, nullptr, nullptr));
-        LCHK(launch_upsplit(c.F(p.dcat[i]), N, h, w, dl.C0, dl.C1, gprev, prev.ptr, prev.scale, prev.shift,
+        LCHK(launch_upsplit(c.F(p.dcat[i]), N, h, w, dl.C0, dl.C1, gprev, pm, prev.scale, prev.shift,
                             dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, st));
       }
       h /= 2; w /= 2;
@@ -689,7 +822,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       };
       auto tensor_grad = [&](int id) -> float* {             // f1..f4 -> gskip[3..0], f5 -> gx of the last encoder block
         if (id < 4) return c.F(p.gskip[3 - id]);
-        if (id == 4) return c.F(p.gx[first_blk[3] + m->stages[3].size() - 1]);
+        if (id == 4) return c.F(p.gx[feat_blk(3)]);
         return c.F(p.g[m->nodes[id - 5].c2]);
       };
       for (int i = (int)m->nodes.size() - 1; i >= 0; --i) {
@@ -708,17 +841,18 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
         else if (nd.skips.size() > 1) { skip = mk_src(c.F(p.cat[i]), nd.C1, nh, nw); sp = &skip; }
         LCHK(run_wgrad(c, nd.c1, prev, sp, c.F(p.g[nd.c1]), nh, nw));
         float* gprev = tensor_grad(nd.prev);
+        const float* pm = nd.prev < 5 ? feat_mask(prev) : prev.ptr;
         const int acc_prev = ginit[nd.prev]; ginit[nd.prev] = 1;
         const ConvL& c1v = m->convs[nd.c1];
         const float* gcat; int gcc, gco;                      // where the skip part of the gradient lands
         if (c1v.wud_off && p.wino_ok((size_t)nd.c1) && !(nh & 1) && !(nw & 1)) {
-          UpSplit us{gprev, nd.C0, prev.ptr, prev.scale, prev.shift, acc_prev};
+          UpSplit us{gprev, nd.C0, pm, prev.scale, prev.shift, acc_prev};
           LCHK(run_dgrad(c, nd.c1, c.F(p.g[nd.c1]), nh, nw, nh, nw, nd.C1 > 0 ? c.F(p.gcat) : nullptr, nullptr, nullptr, nullptr,
                          nullptr, &us));
           gcat = c.F(p.gcat); gcc = nd.C1; gco = 0;
         } else {
           LCHK(run_dgrad(c, nd.c1, c.F(p.g[nd.c1]), nh, nw, nh, nw, c.F(p.dcat[0]), nullptr, nullptr, nullptr, nullptr));
-          LCHK(launch_upsplit(c.F(p.dcat[0]), N, nh, nw, nd.C0, nd.C1, gprev, prev.ptr, prev.scale, prev.shift, nullptr, st, acc_prev));
+          LCHK(launch_upsplit(c.F(p.dcat[0]), N, nh, nw, nd.C0, nd.C1, gprev, pm, prev.scale, prev.shift, nullptr, st, acc_prev));
           gcat = c.F(p.dcat[0]); gcc = nd.C0 + nd.C1; gco = nd.C0;
         }
         int coff = 0;
@@ -734,8 +868,73 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       for (int id = 0; id < 5; ++id) if (!ginit[id]) return fail("internal: UnetPlusPlus feature %d received no gradient", id);
     }
   }
+  // ---------------- EfficientNet encoder: backward stage k handles the blocks between features f_{5-k} and f_{6-k}
+  for (int k = (sb < 1 ? 1 : sb); effnet && k < se && k <= 4; ++k) {
+    const int s = 4 - k;
+    const int lo = s == 0 ? 0 : m->feat_blk[s - 1] + 1;
+    auto bn_ss = [&](int ci, const float** sc, const float** sh_) { const BNL& b = m->bns[m->convs[ci].bn]; *sc = c.F(b.f_off) + 2 * b.C; *sh_ = c.F(b.f_off) + 3 * b.C; };
+    const float *sc, *sf;
+    for (int bi = m->feat_blk[s]; bi >= lo; --bi) {
+      const MBL& b = m->mb[bi];
+      const int ho = p.mh[bi], wo = p.mw[bi], hi = ho * b.stride, wi = wo * b.stride;
+      const size_t npo = (size_t)N * ho * wo, npi = (size_t)N * hi * wi;
+      const float* dz = c.F(p.gx[bi]);                       // grad wrt the block output (complete)
+      float* gO = c.F(p.g[b.cp]); float* gM = c.F(p.g[b.cdw]);
+      const float* rs = (b.skip && b.drop > 0.f && m->keep_fwd) ? m->keep_fwd + (size_t)bi * N : nullptr;
+      const float* g2 = dz;
+      if (rs) { LCHK(launch_rowscale(dz, rs, N, (size_t)ho * wo, b.Cout, gO, st)); g2 = gO; }
+      LCHK(run_bn_bwd(c, b.cp, g2, gO, npo));
+      Src a2 = mk_src(c.F(p.a2[bi]), b.mid, ho, wo);
+      LCHK(run_wgrad(c, b.cp, a2, nullptr, gO, ho, wo));
+      LCHK(run_dgrad(c, b.cp, gO, ho, wo, ho, wo, gM, nullptr, nullptr, nullptr, nullptr));
+      // squeeze-and-excitation: gs = sum_hw g*a1 ; FC backward ; g_a1 = g*s + gpool/hw, then through swish(bn1(.))
+      float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
+      float* gs = c.F(p.se_g); float* gpool = gs + (size_t)N * b.mid;
+      HIPCHK(hipMemsetAsync(gs, 0, (size_t)N * b.mid * sizeof(float), st));
+      LCHK(launch_se_reduce_hw(gM, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, 1.f, gs, st));
+      const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
+      LCHK(launch_se_fc_bwd(gs, sv, hpre, pool, m->params + cr.w_off, cr.Kpad, m->params + cx.w_off, cx.Kpad, N, b.mid, b.nsq,
+                            gpool, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
+      bn_ss(b.cdw, &sc, &sf);
+      LCHK(launch_swish_bwd(gM, c.F(p.y[b.cdw]), sc, sf, b.mid, N, (size_t)ho * wo, sv, gpool, gM, st));
+      LCHK(run_bn_bwd(c, b.cdw, gM, gM, npo));
+      // block input and where its gradient goes
+      Src in = bi == 0 ? f1 : mk_src(c.F(p.xn[bi - 1]), b.Cin, hi, wi);
+      float* gin = bi == 0 ? c.F(p.g[m->stem]) : c.F(p.gx[bi - 1]);
+      const float* addend = nullptr;
+      if (b.skip) addend = dz;                                // identity shortcut
+      else if (bi == 0) addend = c.F(p.gskip[3]);             // f1's gradient from the decoder
+      else for (int fs = 0; fs < 3; ++fs) if (bi - 1 == m->feat_blk[fs]) addend = c.F(p.gskip[2 - fs]);   // f2..f4
+      const ConvL& dw = m->convs[b.cdw];
+      const float* dwin = b.ce >= 0 ? c.F(p.a0[bi]) : in.ptr;
+      {
+        hipStream_t ws_ = st;
+        if (c.wst && c.wst != st) { HIPCHK(hipEventRecord(m->ev_fork, st)); HIPCHK(hipStreamWaitEvent(c.wst, m->ev_fork, 0)); ws_ = c.wst; }
+        LCHK(launch_dw_wgrad(dwin, gM, dw.Kpad, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, m->grads + dw.w_off, ws_));
+      }
+      if (b.ce >= 0) {
+        float* gI = c.F(p.g[b.ce]);
+        LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, dw.Kpad, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, nullptr, gI, st));
+        bn_ss(b.ce, &sc, &sf);
+        LCHK(launch_swish_bwd(gI, c.F(p.y[b.ce]), sc, sf, b.mid, N, (size_t)hi * wi, nullptr, nullptr, gI, st));
+        LCHK(run_bn_bwd(c, b.ce, gI, gI, npi));
+        LCHK(run_wgrad(c, b.ce, in, nullptr, gI, hi, wi));
+        LCHK(run_dgrad(c, b.ce, gI, hi, wi, hi, wi, gin, addend, nullptr, nullptr, nullptr));
+      } else {
+        LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, dw.Kpad, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, addend, gin, st));
+      }
+    }
+    if (s == 0) {
+      float* g = c.F(p.g[m->stem]);
+      bn_ss(m->stem, &sc, &sf);
+      LCHK(launch_swish_bwd(g, c.F(p.y[m->stem]), sc, sf, m->f1C, N, (size_t)h1 * w1, nullptr, nullptr, g, st));
+      LCHK(run_bn_bwd(c, m->stem, g, g, (size_t)N * h1 * w1));
+      Src x4 = mk_src(c.F(p.x4), m->CinP, H, W);
+      LCHK(run_wgrad(c, m->stem, x4, nullptr, g, h1, w1));
+    }
+  }
   // ---------------- encoder stages: backward stage k handles encoder stage s = 4 - k
-  for (int k = (sb < 1 ? 1 : sb); k < se && k <= 4; ++k) {
+  for (int k = (sb < 1 ? 1 : sb); !effnet && k < se && k <= 4; ++k) {
     const int s = 4 - k;
     const int h = sh[s], w = sw[s];
     const size_t npix = (size_t)N * h * w;
@@ -986,6 +1185,7 @@ int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* c
     return fail("uwm_debug_lookup: unknown conv %s", name.c_str());
   }
   auto blk_geo = [&](size_t bi, long long* cnt) {
+    if (!h->mb.empty()) { *cnt = bi < h->mb.size() ? (long long)N * p.mh[bi] * p.mw[bi] * h->mb[bi].Cout : 0; return; }
     int hh = H / 4, ww = W / 4; size_t b = 0;
     for (int s = 0; s < 4; ++s) for (auto& bl : h->stages[s]) {
       hh /= bl.stride; ww /= bl.stride;
@@ -999,6 +1199,7 @@ int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* c
     if (bi >= p.xn.size()) return fail("uwm_debug_lookup: bad block index");
     *off = (long long)(k[0] == 'x' ? p.xn[bi] : p.gx[bi]); blk_geo(bi, count); return 0;
   }
+  if (k == "stem_a") { *off = (long long)p.stem_a; *count = (long long)N * (H / 2) * (W / 2) * h->f1C; return 0; }
   if (k == "pool" || k == "g_pool") { *off = (long long)(k == "pool" ? p.pool : p.g_pool); *count = (long long)N * (H / 4) * (W / 4) * 64; return 0; }
   if (k == "x4") { *off = (long long)p.x4; *count = (long long)N * H * W * h->CinP; return 0; }
   if (k.rfind("dcat:", 0) == 0 || k.rfind("gskip:", 0) == 0) {
@@ -1033,6 +1234,16 @@ static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad
 int uwm_set_join_stream(uwm_handle h, uwm_stream stream) {
   if (!h) return fail("uwm_set_join_stream: null handle");
   h->join_stream = (hipStream_t)stream; return 0;
+}
+int uwm_set_drop_connect(uwm_handle h, const float* rowscale) {
+  if (!h) return fail("uwm_set_drop_connect: null handle");
+  if (rowscale && h->mb.empty()) return fail("uwm_set_drop_connect: the encoder has no MBConv blocks");
+  h->keep = rowscale; return 0;
+}
+int uwm_num_mbconv_blocks(uwm_handle h) { return h ? (int)h->mb.size() : 0; }
+float uwm_mbconv_drop_rate(uwm_handle h, int block) {
+  if (!h || block < 0 || block >= (int)h->mb.size()) return 0.f;
+  return h->mb[block].skip ? h->mb[block].drop : 0.f;
 }
 int uwm_set_winograd(int on) { winograd_set_mode(on < 0 ? 0 : (on > 2 ? 1 : on)); return 0; }
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }

@@ -59,7 +59,7 @@ class _UnetFunction(torch.autograd.Function):
 
 
 class Unet(nn.Module):
-    """MI355X-native U-Net (ResNet-18/34 encoder, smp UnetDecoder, 3x3 segmentation head)."""
+    """MI355X-native U-Net (ResNet-18/34/50 or EfficientNet-b4 encoder, smp UnetDecoder, 3x3 segmentation head)."""
 
     SUPPORTED_ENCODERS = tuple(L.ENC)
     _ARCH = "Unet"
@@ -141,6 +141,12 @@ class Unet(nn.Module):
         self._ws_key = None
         self._fwd_gen = 0
         self._bound = None
+        # EfficientNet encoders: stochastic depth of the MBConv blocks (efficientnet_pytorch drop_connect_rate 0.2)
+        self._n_mb = lib.uwm_num_mbconv_blocks(h)
+        self._mb_drop = [float(lib.uwm_mbconv_drop_rate(h, i)) for i in range(self._n_mb)]
+        self.drop_connect = self._n_mb > 0
+        self._keep_override = None        # tests: {0,1} keep masks [n_blocks, N] instead of a random draw
+        self._rowscale = None
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init
@@ -152,7 +158,10 @@ class Unet(nn.Module):
                 p = self._plist[pi]; pi += 1
                 if kind == L.KIND_CONV_W:
                     w = torch.empty(shape, dtype=torch.float32)
-                    if name.startswith("encoder."):
+                    fan_in = shape[1] * shape[2] * shape[3]
+                    if name.startswith("encoder._"):        # efficientnet_pytorch keeps torch's default Conv2d init
+                        nn.init.kaiming_uniform_(w, a=5 ** 0.5)
+                    elif name.startswith("encoder."):
                         nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
                     elif name.startswith("decoder."):
                         nn.init.kaiming_uniform_(w, mode="fan_in", nonlinearity="relu")
@@ -161,6 +170,9 @@ class Unet(nn.Module):
                     p.copy_(w.to(p.device))
                 elif kind == L.KIND_BN_GAMMA:
                     p.fill_(1.0)
+                elif kind == L.KIND_BIAS and name.startswith("encoder._"):   # default Conv2d bias init (SE layers)
+                    bound = 1.0 / fan_in ** 0.5
+                    p.copy_(torch.empty(shape, dtype=torch.float32).uniform_(-bound, bound).to(p.device))
                 else:
                     p.zero_()
         for node, leaf, off, shape, stride in self._binfo:
@@ -255,12 +267,29 @@ class Unet(nn.Module):
         ws = self._workspace(n, h, w, training)
         logits = torch.empty((n, h, w, self._cp), dtype=torch.float32, device=x.device)
         self._fwd_gen += 1
+        if self._n_mb:
+            self._set_drop_connect(n, training, x.device)
         L.check(L.lib().uwm_forward(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(logits.data_ptr()),
                                     C.c_void_p(ws.data_ptr()), ws.numel(), n, h, w, int(training),
                                     C.c_void_p(L.stream_ptr(x.device))), SegmentationModelError)
         if training:
             self._nbt_arena += 1
         return logits
+
+    def _set_drop_connect(self, n: int, training: bool, device):
+        """Draw this step's per-block, per-sample keep masks (efficientnet_pytorch utils.drop_connect: floor(keep_prob +
+        U[0,1)) / keep_prob) on the device and hand them to the library; the tensor lives until the next forward."""
+        if not (training and self.drop_connect):
+            self._rowscale = None
+            L.check(L.lib().uwm_set_drop_connect(self._h, None))
+            return
+        keep_prob = 1.0 - torch.tensor(self._mb_drop, dtype=torch.float32, device=device).view(-1, 1)
+        if self._keep_override is not None:
+            keep = self._keep_override.to(device=device, dtype=torch.float32).reshape(self._n_mb, n)
+        else:
+            keep = torch.floor(keep_prob + torch.rand((self._n_mb, n), dtype=torch.float32, device=device))
+        self._rowscale = (keep / keep_prob).contiguous()
+        L.check(L.lib().uwm_set_drop_connect(self._h, C.c_void_p(self._rowscale.data_ptr())))
 
     def _backward_raw(self, dlogits: torch.Tensor, stage_begin: int = 0, stage_end: Optional[int] = None):
         """dlogits [N,H,W,CP] (padding channels zero) -> gradient arena (overwritten)."""
