@@ -7,6 +7,7 @@
 // Reference semantics: efficientnet_pytorch MBConvBlock as vendored by segmentation_models_pytorch
 // (/root/reference/src/models/unet_model.py:64-71 with ENCODER_NAME efficientnet-b4).
 #include "uwm_kernels.h"
+#include <algorithm>
 
 namespace uwm {
 
@@ -59,112 +60,240 @@ hipError_t launch_swish_bwd(const float* g, const float* y, const float* sc, con
 }
 
 // ---------------------------------------------------------------- depthwise convolution
-// x [N][H][W][C] (plain), w [C][Kpad] with tap t of channel c at w[c*Kpad + t*4]; pb = pad at the begin of H and W
-__global__ void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int Kpad, int k, int stride, int pb,
-                              int H, int W, int C, int Ho, int Wo, float* __restrict__ y, size_t total) {
-  const int C4 = C / 4;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4; size_t p = i / C4;
-    const int wo = (int)(p % Wo); p /= Wo;
-    const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < k; ++r) {
-      const int hi = ho * stride - pb + r;
-      if (hi < 0 || hi >= H) continue;
-      for (int s = 0; s < k; ++s) {
-        const int wi = wo * stride - pb + s;
-        if (wi < 0 || wi >= W) continue;
-        const f4 xv = *(const f4*)(x + (((size_t)n * H + hi) * W + wi) * C + c);
-        const int t = (r * k + s) * 4;
-        const f4 wv = {w[(size_t)c * Kpad + t], w[(size_t)(c + 1) * Kpad + t], w[(size_t)(c + 2) * Kpad + t], w[(size_t)(c + 3) * Kpad + t]};
-        acc += xv * wv;
+// x [N][H][W][C] plain NHWC; w [k*k][C] (tap-major: tap t of channel c at w[t*C + c], the parameter-arena layout of a
+// depthwise layer, so a thread's four channels of one tap are ONE 16-byte load); pb = zero pad at the begin of H and W
+// (the end pad is implied by Ho / Wo).  HBM-bound: a thread owns (channel quad, output column), keeps its k*k*4 weights
+// in registers and walks down the image in bands of TH output rows, so every input element is loaded ~(TH*S+K-S)/(TH*S)
+// times per column tap instead of K times; lanes run along (column, channel) = contiguous memory.
+template <int K, int S, int TH>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int flip, int pb, int H, int W,
+                                                     int C, int Ho, int Wo, const float* __restrict__ addend, float* __restrict__ y) {
+  const int C4 = C >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wo * C4) return;
+  const int wo = idx / C4, c = (idx - wo * C4) * 4;
+  const int n = blockIdx.z;
+  f4 wr[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wr[t] = *(const f4*)(w + (size_t)(flip ? K * K - 1 - t : t) * C + c);
+  const float* xn = x + (size_t)n * H * W * C + c;
+  const int wi0 = wo * S - pb;
+  constexpr int R = (TH - 1) * S + K;
+  for (int ho0 = blockIdx.y * TH; ho0 < Ho; ho0 += gridDim.y * TH) {
+    f4 acc[TH];
+#pragma unroll
+    for (int j = 0; j < TH; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int hi0 = ho0 * S - pb;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+      const int hi = hi0 + rr;
+      if (hi < 0 || hi >= H) continue;               // uniform over the workgroup
+      const float* row = xn + (size_t)hi * W * C;
+      f4 xv[K];
+#pragma unroll
+      for (int s_ = 0; s_ < K; ++s_) {
+        const int wi = wi0 + s_;
+        xv[s_] = (wi >= 0 && wi < W) ? *(const f4*)(row + (size_t)wi * C) : (f4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < TH; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int r = rr - j * S;                    // compile-time after unrolling
+        if (r >= 0 && r < K) {
+#pragma unroll
+          for (int s_ = 0; s_ < K; ++s_) acc[j] += xv[s_] * wr[r * K + s_];
+        }
       }
     }
-    *(f4*)(y + i * 4) = acc;
-  }
-}
-hipError_t launch_dw_fwd(const float* x, const float* w, int Kpad, int k, int stride, int pb, int N, int H, int W, int C,
-                         int Ho, int Wo, float* y, hipStream_t st) {
-  const size_t total = (size_t)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(nb(total, 256)), dim3(256), 0, st, x, w, Kpad, k, stride, pb, H, W, C, Ho, Wo, y, total);
-  return hipGetLastError();
-}
-// dx[n][h][w][c] = sum over taps with (h + pb - r) divisible by stride of dy[n][(h+pb-r)/stride][..][c] * w[c][r][s]
-__global__ void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, int Kpad, int k, int stride, int pb,
-                                int H, int W, int C, int Ho, int Wo, const float* __restrict__ addend, float* __restrict__ dx, size_t total) {
-  const int C4 = C / 4;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4; size_t p = i / C4;
-    const int wi = (int)(p % W); p /= W;
-    const int hi = (int)(p % H); const int n = (int)(p / H);
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < k; ++r) {
-      const int hn = hi + pb - r;
-      if (hn < 0 || (hn % stride) != 0) continue;
-      const int ho = hn / stride;
-      if (ho >= Ho) continue;
-      for (int s = 0; s < k; ++s) {
-        const int wn = wi + pb - s;
-        if (wn < 0 || (wn % stride) != 0) continue;
-        const int wo = wn / stride;
-        if (wo >= Wo) continue;
-        const f4 gv = *(const f4*)(dy + (((size_t)n * Ho + ho) * Wo + wo) * C + c);
-        const int t = (r * k + s) * 4;
-        const f4 wv = {w[(size_t)c * Kpad + t], w[(size_t)(c + 1) * Kpad + t], w[(size_t)(c + 2) * Kpad + t], w[(size_t)(c + 3) * Kpad + t]};
-        acc += gv * wv;
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int ho = ho0 + j;
+      if (ho < Ho) {
+        const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+        f4 v = acc[j];
+        if (addend) v += *(const f4*)(addend + o);
+        *(f4*)(y + o) = v;
       }
     }
-    if (addend) acc += *(const f4*)(addend + i * 4);
-    *(f4*)(dx + i * 4) = acc;
   }
 }
-hipError_t launch_dw_dgrad(const float* dy, const float* w, int Kpad, int k, int stride, int pb, int N, int H, int W, int C,
-                           int Ho, int Wo, const float* addend, float* dx, hipStream_t st) {
-  const size_t total = (size_t)N * H * W * (C / 4);
-  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(nb(total, 256)), dim3(256), 0, st, dy, w, Kpad, k, stride, pb, H, W, C, Ho, Wo, addend, dx, total);
+static inline void dw_grid(int cols_c4, int nbands, int N, dim3* g) {
+  const unsigned gx = (unsigned)((cols_c4 + 255) / 256);
+  unsigned gy = (unsigned)std::max(1, std::min(nbands, (int)(4096 / std::max(1u, gx * (unsigned)N))));
+  *g = dim3(gx, gy, (unsigned)N);
+}
+template <int K, int S, int TH>
+static hipError_t dw_fwd_launch(const float* x, const float* w, int flip, int pb, int N, int H, int W, int C, int Ho, int Wo,
+                                const float* addend, float* y, hipStream_t st) {
+  dim3 g; dw_grid(Wo * (C / 4), (Ho + TH - 1) / TH, N, &g);
+  hipLaunchKernelGGL((dw_fwd_kernel<K, S, TH>), g, dim3(256), 0, st, x, w, flip, pb, H, W, C, Ho, Wo, addend, y);
   return hipGetLastError();
 }
-// dw[c][tap] += sum over output pixels dy[pix][c] * x[pix*stride - pb + tap][c]; blockIdx.y = tap; a block strides over
-// output pixels with (256 / (C/4)) pixel lanes per channel quad, LDS reduce, one atomic per (channel, tap) per block
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int Kpad, int k, int stride,
-                                                       int pb, int H, int W, int C, int Ho, int Wo, int N, int CW, float* __restrict__ dw) {
-  __shared__ float red[256 * 4];
-  const int tap = blockIdx.y, r = tap / k, s = tap - r * k;
-  const int c0 = blockIdx.z * CW;
-  const int tc = CW / 4, tr = 256 / tc;
-  const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
-  const int c = c0 + cx * 4;
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
-  const size_t npix = (size_t)N * Ho * Wo;
-  if (rx < tr) {
-    for (size_t p = (size_t)blockIdx.x * tr + rx; p < npix; p += (size_t)gridDim.x * tr) {
-      const int wo = (int)(p % Wo); size_t q = p / Wo;
-      const int ho = (int)(q % Ho); const int n = (int)(q / Ho);
-      const int hi = ho * stride - pb + r, wi = wo * stride - pb + s;
-      if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-      acc += *(const f4*)(dy + p * C + c) * *(const f4*)(x + (((size_t)n * H + hi) * W + wi) * C + c);
+hipError_t launch_dw_fwd(const float* x, const float* w, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
+                         float* y, hipStream_t st) {
+  if (C & 3) return hipErrorInvalidValue;
+  if (k == 3 && stride == 1) return dw_fwd_launch<3, 1, 8>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 3 && stride == 2) return dw_fwd_launch<3, 2, 4>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 5 && stride == 1) return dw_fwd_launch<5, 1, 8>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 5 && stride == 2) return dw_fwd_launch<5, 2, 4>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  return hipErrorInvalidValue;
+}
+
+// stride-2 dgrad: dx[hi][wi] = sum over (r, s) with (hi + pb - r), (wi + pb - s) even of dy[(hi+pb-r)/2][(wi+pb-s)/2] * w[r][s].
+// A thread owns (channel quad, input column wi) and bands of TH = 8 dx rows; per band it visits the NQ dy rows that
+// touch the band; with hi0 even, r = j + E - 2q for dx row j and dy row q, E = K-1 + (pb & 1) (template PBODD).
+template <int K, int PBODD>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w, int pb, int H, int W, int C,
+                                                          int Ho, int Wo, const float* __restrict__ addend, float* __restrict__ dx) {
+  constexpr int TH = 8, E = K - 1 + PBODD, NQ = (TH - 1 + E) / 2 + 1;
+  const int C4 = C >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= W * C4) return;
+  const int wi = idx / C4, c = (idx - wi * C4) * 4;
+  const int n = blockIdx.z;
+  f4 wr[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wr[t] = *(const f4*)(w + (size_t)t * C + c);
+  const float* gn = dy + (size_t)n * Ho * Wo * C + c;
+  for (int hi0 = blockIdx.y * TH; hi0 < H; hi0 += gridDim.y * TH) {
+    f4 acc[TH];
+#pragma unroll
+    for (int j = 0; j < TH; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int hob = (hi0 + pb - (K - 1)) >> 1;       // arithmetic shift: floor
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int ho = hob + q;
+      if (ho < 0 || ho >= Ho) continue;              // uniform
+      const float* row = gn + (size_t)ho * Wo * C;
+#pragma unroll
+      for (int s_ = 0; s_ < K; ++s_) {
+        const int wn = wi + pb - s_;
+        const bool ok = wn >= 0 && !(wn & 1) && (wn >> 1) < Wo;
+        const f4 g = ok ? *(const f4*)(row + (size_t)(wn >> 1) * C) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+          const int r = j + E - 2 * q;               // compile-time
+          if (r >= 0 && r < K) acc[j] += g * wr[r * K + s_];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int hi = hi0 + j;
+      if (hi < H) {
+        const size_t o = (((size_t)n * H + hi) * W + wi) * C + c;
+        f4 v = acc[j];
+        if (addend) v += *(const f4*)(addend + o);
+        *(f4*)(dx + o) = v;
+      }
     }
   }
-  float* rr = red + threadIdx.x * 4;
-  rr[0] = acc.x; rr[1] = acc.y; rr[2] = acc.z; rr[3] = acc.w;
-  __syncthreads();
-  for (int t = threadIdx.x; t < tc * 4; t += 256) {
-    const int q = t / 4, e = t % 4;
-    float sum = 0.f;
-    for (int kk = 0; kk < tr; ++kk) sum += red[(kk * tc + q) * 4 + e];
-    atomicAdd(dw + (size_t)(c0 + q * 4 + e) * Kpad + tap * 4, sum);
+}
+hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
+                           const float* addend, float* dx, hipStream_t st) {
+  if (C & 3) return hipErrorInvalidValue;
+  if (stride == 1) {                                 // correlation with the flipped filter, pad k-1-pb
+    if (k == 3) return dw_fwd_launch<3, 1, 8>(dy, w, 1, k - 1 - pb, N, Ho, Wo, C, H, W, addend, dx, st);
+    if (k == 5) return dw_fwd_launch<5, 1, 8>(dy, w, 1, k - 1 - pb, N, Ho, Wo, C, H, W, addend, dx, st);
+    return hipErrorInvalidValue;
+  }
+  if (stride != 2 || (k != 3 && k != 5)) return hipErrorInvalidValue;
+  dim3 g; dw_grid(W * (C / 4), (H + 7) / 8, N, &g);
+  if (k == 3 && !(pb & 1)) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3, 0>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
+  else if (k == 3) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3, 1>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
+  else if (!(pb & 1)) hipLaunchKernelGGL((dw_dgrad_s2_kernel<5, 0>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
+  else hipLaunchKernelGGL((dw_dgrad_s2_kernel<5, 1>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
+  return hipGetLastError();
+}
+
+// dw[tap][c] += sum over output pixels dy[pix][c] * x[pix*S - pb + tap][c].  Same walk as the forward kernel (thread =
+// channel quad x output column, bands of TH rows) with the k*k*4 partial sums in registers; at the end the partials of
+// the workgroup's threads that share a channel are combined in LDS (ds_add_f32) when the workgroup covers each channel
+// more than once (C/4 < 256), then one global atomic per (tap, channel) and workgroup.
+template <int K, int S, int TH>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int pb, int H, int W, int C,
+                                                       int Ho, int Wo, int use_lds, float* __restrict__ dw) {
+  extern __shared__ float red[];                     // [K*K][C] when use_lds
+  const int C4 = C >> 2;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < K * K * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+  }
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < Wo * C4;
+  const int wo = live ? idx / C4 : 0, c = live ? (idx - wo * C4) * 4 : 0;
+  const int n = blockIdx.z;
+  f4 acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const float* xn = x + (size_t)n * H * W * C + c;
+    const float* gn = dy + (size_t)n * Ho * Wo * C + (size_t)wo * C + c;
+    const int wi0 = wo * S - pb;
+    constexpr int R = (TH - 1) * S + K;
+    for (int ho0 = blockIdx.y * TH; ho0 < Ho; ho0 += gridDim.y * TH) {
+      f4 gv[TH];
+#pragma unroll
+      for (int j = 0; j < TH; ++j) gv[j] = (ho0 + j < Ho) ? *(const f4*)(gn + (size_t)(ho0 + j) * Wo * C) : (f4){0.f, 0.f, 0.f, 0.f};
+      const int hi0 = ho0 * S - pb;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        const int hi = hi0 + rr;
+        if (hi < 0 || hi >= H) continue;
+        const float* row = xn + (size_t)hi * W * C;
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {
+          const int wi = wi0 + s_;
+          const f4 xv = (wi >= 0 && wi < W) ? *(const f4*)(row + (size_t)wi * C) : (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < TH; ++j) {
+            const int r = rr - j * S;
+            if (r >= 0 && r < K) acc[r * K + s_] += gv[j] * xv;
+          }
+        }
+      }
+    }
+  }
+  if (use_lds) {
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < K * K; ++t) {
+        float* d = red + t * C + c;
+        atomicAdd(d, acc[t].x); atomicAdd(d + 1, acc[t].y); atomicAdd(d + 2, acc[t].z); atomicAdd(d + 3, acc[t].w);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K * C; i += 256) { const float v = red[i]; if (v != 0.f) atomicAdd(dw + i, v); }
+  } else if (live) {
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      float* d = dw + (size_t)t * C + c;
+      atomicAdd(d, acc[t].x); atomicAdd(d + 1, acc[t].y); atomicAdd(d + 2, acc[t].z); atomicAdd(d + 3, acc[t].w);
+    }
   }
 }
-hipError_t launch_dw_wgrad(const float* x, const float* dy, int Kpad, int k, int stride, int pb, int N, int H, int W, int C,
-                           int Ho, int Wo, float* dw, hipStream_t st) {
-  const int CW = pick_cw(C);
-  if (!CW) return hipErrorInvalidValue;
-  const int tr = 256 / (CW / 4);
-  const size_t npix = (size_t)N * Ho * Wo;
-  unsigned bx = (unsigned)((npix + (size_t)tr * 64 - 1) / ((size_t)tr * 64));
-  if (bx > 512) bx = 512; if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(dw_wgrad_kernel, dim3(bx, k * k, C / CW), dim3(256), 0, st, x, dy, Kpad, k, stride, pb, H, W, C, Ho, Wo, N, CW, dw);
+template <int K, int S, int TH>
+static hipError_t dw_wgrad_launch(const float* x, const float* dy, int pb, int N, int H, int W, int C, int Ho, int Wo, float* dw,
+                                  hipStream_t st) {
+  const int use_lds = (C / 4) < 256;
+  const size_t lds = use_lds ? (size_t)K * K * C * sizeof(float) : 0;
+  if (lds > 64 * 1024) {
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_kernel<K, S, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; }
+  }
+  dim3 g; dw_grid(Wo * (C / 4), (Ho + TH - 1) / TH, N, &g);
+  g.y = std::max(1u, std::min(g.y, 1024u / std::max(1u, g.x * g.z)));     // fewer, longer workgroups: the tail is one atomic per (tap, channel)
+  hipLaunchKernelGGL((dw_wgrad_kernel<K, S, TH>), g, dim3(256), lds, st, x, dy, pb, H, W, C, Ho, Wo, use_lds, dw);
   return hipGetLastError();
+}
+hipError_t launch_dw_wgrad(const float* x, const float* dy, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
+                           float* dw, hipStream_t st) {
+  if (C & 3) return hipErrorInvalidValue;
+  if (k == 3 && stride == 1) return dw_wgrad_launch<3, 1, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
+  if (k == 3 && stride == 2) return dw_wgrad_launch<3, 2, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
+  if (k == 5 && stride == 1) return dw_wgrad_launch<5, 1, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
+  if (k == 5 && stride == 2) return dw_wgrad_launch<5, 2, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------- per-channel sum / sum of squares (BatchNorm statistics)
@@ -236,77 +365,96 @@ hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw,
   hipLaunchKernelGGL(se_reduce_hw_kernel, dim3(bx, N, C / CW), dim3(256), 0, st, a, b, hw, C, CW, scale, out);
   return hipGetLastError();
 }
-// one block per sample: hid = swish(W1 pool + b1) (pre-activation kept in `hpre`), s = sigmoid(W2 hid + b2)
-// W1 [nsq][K1pad] over C channels, W2 [C][K2pad] over nsq
+// SE FCs, forward.  grid (N, ceil(C/256)): every workgroup recomputes the nsq hidden units of its sample (a wave per
+// unit: lanes along the C inputs, coalesced row reads of W1 [nsq][K1pad], shuffle reduce), then one thread per output
+// channel of its 256-channel slice (row of W2 [C][K2pad], 16-byte loads).  hid = swish(W1 pool + b1) (pre-activation
+// kept in hpre), s = sigmoid(W2 hid + b2).
 __global__ __launch_bounds__(256) void se_fc_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ b1,
                                                         int K1pad, const float* __restrict__ w2, const float* __restrict__ b2, int K2pad,
                                                         int C, int nsq, float* __restrict__ hpre, float* __restrict__ s) {
-  extern __shared__ float sh[];        // [nsq] hidden (post-swish)
-  const int n = blockIdx.x;
+  extern __shared__ float sh[];        // [rup(nsq,4)] hidden (post-swish), zero padded
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nsqP = (nsq + 3) & ~3;
   const float* p = pool + (size_t)n * C;
-  for (int j = threadIdx.x; j < nsq; j += blockDim.x) {
-    float acc = b1[j];
-    for (int c = 0; c < C; ++c) acc += w1[(size_t)j * K1pad + c] * p[c];
-    hpre[(size_t)n * nsq + j] = acc;
-    sh[j] = acc * sigm(acc);
+  for (int j = wv; j < nsqP; j += 4) {
+    float acc = 0.f;
+    if (j < nsq) for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * K1pad + c] * p[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+      float h = 0.f;
+      if (j < nsq) { acc += b1[j]; h = acc * sigm(acc); if (blockIdx.y == 0) hpre[(size_t)n * nsq + j] = acc; }
+      sh[j] = h;
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c < C) {
     float acc = b2[c];
-    for (int j = 0; j < nsq; ++j) acc += w2[(size_t)c * K2pad + j] * sh[j];
+    const float* row = w2 + (size_t)c * K2pad;
+    for (int j = 0; j < nsqP; j += 4) { const f4 wv4 = *(const f4*)(row + j); acc += wv4.x * sh[j] + wv4.y * sh[j + 1] + wv4.z * sh[j + 2] + wv4.w * sh[j + 3]; }
     s[(size_t)n * C + c] = sigm(acc);
   }
 }
 hipError_t launch_se_fc_fwd(const float* pool, const float* w1, const float* b1, int K1pad, const float* w2, const float* b2,
                             int K2pad, int N, int C, int nsq, float* hpre, float* s, hipStream_t st) {
-  hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(N), dim3(256), nsq * sizeof(float), st, pool, w1, b1, K1pad, w2, b2, K2pad, C, nsq, hpre, s);
+  hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(N, (C + 255) / 256), dim3(256), ((nsq + 3) & ~3) * sizeof(float), st, pool, w1, b1, K1pad,
+                     w2, b2, K2pad, C, nsq, hpre, s);
   return hipGetLastError();
 }
-// backward of the two FCs for one sample per block: gs[n][c] = dL/ds ; writes gpool[n][c] = dL/dpool and accumulates
-// the four parameter gradients with atomics
-__global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s, const float* __restrict__ hpre,
-                                                        const float* __restrict__ pool, const float* __restrict__ w1, int K1pad,
-                                                        const float* __restrict__ w2, int K2pad, int C, int nsq, float* __restrict__ gpool,
-                                                        float* gw1, float* gb1, float* gw2, float* gb2) {
-  extern __shared__ float sh[];        // [C] gz2 ; [nsq] hid ; [nsq] gz1
-  float* gz2 = sh; float* hid = sh + C; float* gz1 = hid + nsq;
+// SE FCs, backward, two launches and no global atomics.  (A) per sample: gz2 = gs * s(1-s) (in place over gs),
+// hid = swish(hpre), gz1 = (W2^T gz2) * swish'(hpre) — the W2^T product walks W2 rows (thread per channel) and adds into
+// nsq LDS accumulators, each lane starting at a different unit so the ds_add_f32 of a wave hit different addresses.
+// (B) over all samples: gW2 = sum_n gz2 hid^T, gW1 = sum_n gz1 pool^T, gb2, gb1 (plain stores: the gradient arena is
+// zeroed per backward and nothing else writes these tensors) and gpool = W1^T gz1.
+__global__ __launch_bounds__(256) void se_fc_bwd_a_kernel(float* __restrict__ gs, const float* __restrict__ s, const float* __restrict__ hpre,
+                                                          const float* __restrict__ w2, int K2pad, int C, int nsq, float* __restrict__ hid,
+                                                          float* __restrict__ gz1) {
+  extern __shared__ float sh[];        // [nsq] accumulators
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int j = threadIdx.x; j < nsq; j += 256) sh[j] = 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
     const float sv = s[(size_t)n * C + c];
-    const float g = gs[(size_t)n * C + c] * sv * (1.f - sv);        // through the sigmoid
-    gz2[c] = g;
-    atomicAdd(gb2 + c, g);
-  }
-  for (int j = threadIdx.x; j < nsq; j += blockDim.x) { const float z = hpre[(size_t)n * nsq + j]; hid[j] = z * sigm(z); }
-  __syncthreads();
-  for (int i = threadIdx.x; i < C * nsq; i += blockDim.x) {           // gW2[c][j] += gz2[c] * hid[j]
-    const int c = i / nsq, j = i - c * nsq;
-    atomicAdd(gw2 + (size_t)c * K2pad + j, gz2[c] * hid[j]);
-  }
-  for (int j = threadIdx.x; j < nsq; j += blockDim.x) {
-    float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc += w2[(size_t)c * K2pad + j] * gz2[c];
-    const float g = acc * dswish(hpre[(size_t)n * nsq + j]);
-    gz1[j] = g;
-    atomicAdd(gb1 + j, g);
+    const float g = gs[(size_t)n * C + c] * sv * (1.f - sv);
+    gs[(size_t)n * C + c] = g;
+    const float* row = w2 + (size_t)c * K2pad;
+    int j = threadIdx.x % nsq;
+    for (int jj = 0; jj < nsq; ++jj) { atomicAdd(&sh[j], row[j] * g); if (++j == nsq) j = 0; }
   }
   __syncthreads();
-  const float* p = pool + (size_t)n * C;
-  for (int i = threadIdx.x; i < nsq * C; i += blockDim.x) {           // gW1[j][c] += gz1[j] * pool[c]
-    const int j = i / C, c = i - j * C;
-    atomicAdd(gw1 + (size_t)j * K1pad + c, gz1[j] * p[c]);
-  }
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc = 0.f;
-    for (int j = 0; j < nsq; ++j) acc += w1[(size_t)j * K1pad + c] * gz1[j];
-    gpool[(size_t)n * C + c] = acc;
+  for (int j = threadIdx.x; j < nsq; j += 256) {
+    const float z = hpre[(size_t)n * nsq + j];
+    hid[(size_t)n * nsq + j] = z * sigm(z);
+    gz1[(size_t)n * nsq + j] = sh[j] * dswish(z);
   }
 }
-hipError_t launch_se_fc_bwd(const float* gs, const float* s, const float* hpre, const float* pool, const float* w1, int K1pad,
-                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* gw1, float* gb1, float* gw2,
-                            float* gb2, hipStream_t st) {
-  hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N), dim3(256), (C + 2 * nsq) * sizeof(float), st, gs, s, hpre, pool, w1, K1pad, w2, K2pad,
-                     C, nsq, gpool, gw1, gb1, gw2, gb2);
+__global__ __launch_bounds__(256) void se_fc_bwd_b_kernel(const float* __restrict__ gz2, const float* __restrict__ hid, const float* __restrict__ gz1,
+                                                          const float* __restrict__ pool, const float* __restrict__ w1, int K1pad, int K2pad,
+                                                          int N, int C, int nsq, float* __restrict__ gpool, float* __restrict__ gw1,
+                                                          float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < C * nsq) {
+    { const int c = i / nsq, j = i - c * nsq; float a = 0.f; for (int n = 0; n < N; ++n) a += gz2[(size_t)n * C + c] * hid[(size_t)n * nsq + j]; gw2[(size_t)c * K2pad + j] = a; }
+    { const int j = i / C, c = i - j * C; float a = 0.f; for (int n = 0; n < N; ++n) a += gz1[(size_t)n * nsq + j] * pool[(size_t)n * C + c]; gw1[(size_t)j * K1pad + c] = a; }
+  }
+  if (i < C) { float a = 0.f; for (int n = 0; n < N; ++n) a += gz2[(size_t)n * C + i]; gb2[i] = a; }
+  if (i < nsq) { float a = 0.f; for (int n = 0; n < N; ++n) a += gz1[(size_t)n * nsq + i]; gb1[i] = a; }
+  if (i < N * C) {
+    const int n = i / C, c = i - n * C;
+    float a = 0.f;
+    for (int j = 0; j < nsq; ++j) a += w1[(size_t)j * K1pad + c] * gz1[(size_t)n * nsq + j];
+    gpool[i] = a;
+  }
+}
+// gs [N][C] is overwritten with gz2; hid / gz1: scratch [N][nsq] each
+hipError_t launch_se_fc_bwd(float* gs, const float* s, const float* hpre, const float* pool, const float* w1, int K1pad,
+                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* hid, float* gz1, float* gw1,
+                            float* gb1, float* gw2, float* gb2, hipStream_t st) {
+  hipLaunchKernelGGL(se_fc_bwd_a_kernel, dim3(N), dim3(256), nsq * sizeof(float), st, gs, s, hpre, w2, K2pad, C, nsq, hid, gz1);
+  const int work = std::max(C * nsq, N * C);
+  hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3((work + 255) / 256), dim3(256), 0, st, gs, hid, gz1, pool, w1, K1pad, K2pad, N, C, nsq,
+                     gpool, gw1, gb1, gw2, gb2);
   return hipGetLastError();
 }
 // out[n][hw][c] = a[n][hw][c] * s[n][c]

@@ -151,26 +151,27 @@ hipError_t launch_preprocess_u8(const uint8_t* img, int N, int H, int W, int C, 
                                 const int* flags, float* out, hipStream_t st);
 hipError_t launch_preprocess_mask(const uint8_t* m, int N, int H, int W, int thr, const int* flags, uint8_t* out, hipStream_t st);
 
-// EfficientNet MBConv pieces (mbconv.hip): swish, depthwise k x k conv with static "same" padding (pb = pad at the
-// begin of H and W; the end pad is implied by Ho/Wo), squeeze-and-excitation, block output with drop-connect
+// EfficientNet MBConv pieces (mbconv.hip): swish, depthwise k x k conv (weights tap-major [k*k][C]) with static "same"
+// padding (pb = pad at the begin of H and W; the end pad is implied by Ho/Wo), squeeze-and-excitation, block output with drop-connect
 hipError_t launch_swish_fwd(const float* y, const float* sc, const float* sh, int C, float* out, size_t npix, hipStream_t st);
 // out = g' * swish'(y*sc+sh), g' = g (se_s == nullptr) or g*se_s[n][c] + gpool[n][c]/hw (SE backward folded in)
 hipError_t launch_swish_bwd(const float* g, const float* y, const float* sc, const float* sh, int C, int N, size_t hw,
                             const float* se_s, const float* gpool, float* out, hipStream_t st);
-hipError_t launch_dw_fwd(const float* x, const float* w, int Kpad, int k, int stride, int pb, int N, int H, int W, int C,
+hipError_t launch_dw_fwd(const float* x, const float* w, int k, int stride, int pb, int N, int H, int W, int C,
                          int Ho, int Wo, float* y, hipStream_t st);
-hipError_t launch_dw_dgrad(const float* dy, const float* w, int Kpad, int k, int stride, int pb, int N, int H, int W, int C,
+hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, int pb, int N, int H, int W, int C,
                            int Ho, int Wo, const float* addend, float* dx, hipStream_t st);
-hipError_t launch_dw_wgrad(const float* x, const float* dy, int Kpad, int k, int stride, int pb, int N, int H, int W, int C,
+hipError_t launch_dw_wgrad(const float* x, const float* dy, int k, int stride, int pb, int N, int H, int W, int C,
                            int Ho, int Wo, float* dw, hipStream_t st);
 hipError_t launch_colstats(const float* y, size_t npix, int C, double* ssum, double* ssq, hipStream_t st);
 // out[n][c] += scale * sum_hw a[n][hw][c] (* b[n][hw][c]); out zeroed by the caller
 hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, hipStream_t st);
 hipError_t launch_se_fc_fwd(const float* pool, const float* w1, const float* b1, int K1pad, const float* w2, const float* b2,
                             int K2pad, int N, int C, int nsq, float* hpre, float* s, hipStream_t st);
-hipError_t launch_se_fc_bwd(const float* gs, const float* s, const float* hpre, const float* pool, const float* w1, int K1pad,
-                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* gw1, float* gb1, float* gw2,
-                            float* gb2, hipStream_t st);
+// gs [N][C] is overwritten (gz2); hid / gz1: scratch [N][nsq] each; parameter gradients are plain stores
+hipError_t launch_se_fc_bwd(float* gs, const float* s, const float* hpre, const float* pool, const float* w1, int K1pad,
+                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* hid, float* gz1, float* gw1,
+                            float* gb1, float* gw2, float* gb2, hipStream_t st);
 hipError_t launch_se_scale(const float* a, const float* s, int N, size_t hw, int C, float* out, hipStream_t st);
 // out = (y*sc+sh) * rowscale[n] + id   (rowscale / id may be nullptr)
 hipError_t launch_mb_out(const float* y, const float* sc, const float* sh, const float* rowscale, const float* id, int N, size_t hw,

@@ -43,6 +43,8 @@ struct BNL {
 struct ConvL {
   std::string name; int Cin, CinP, Cout, CoutP, k, stride, pad, Kpad, KpadD, stage;
   long long w_off, bias_off; int bn; bool dgrad;
+  bool dw = false;                 // depthwise layer (Cin = 1 per group): weights tap-major [k*k][Cout] in the arena
+  long long wfloats() const { return dw ? (long long)k * k * CoutP : (long long)Cout * Kpad; }
   size_t wd_off;                   // workspace floats: [CinP][KpadD] dgrad repack
   size_t wu_off, wud_off;          // workspace floats: Winograd-transformed weights (forward / dgrad); 0 = none
   bool wino() const { return k == 3 && stride == 1 && pad == 1 && (CinP & 7) == 0; }
@@ -70,7 +72,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   size_t stem_a = 0;                // EfficientNet: materialised stem feature f1 = swish(bn(conv_stem))
   std::vector<size_t> a0, a1, a2, se;   // EfficientNet per block: swish(bn0(expand)), swish(bn1(dw)), SE-scaled, {pool[N][mid], s[N][mid], hpre[N][nsqP]}
   std::vector<int> mh, mw;          // EfficientNet per block: output height / width
-  size_t se_g = 0;                  // EfficientNet: SE backward scratch {gs[N][maxmid], gpool[N][maxmid]}
+  size_t se_g = 0, se_gn = 0;       // EfficientNet: SE backward scratch {gs, gpool: se_gn floats each; hid, gz1: N*max nsq each}
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
@@ -199,6 +201,7 @@ static int build_model(uwm_model* m) {
         if (stg[sg].expand != 1) b.ce = add_conv(m, P + "._expand_conv", b.Cin, b.mid, 1, 1, 0, stage, true, P + "._bn0", false, be, bm);
         b.pb = same_pad(size, b.k, b.stride, &osz); size = osz;
         b.cdw = add_conv(m, P + "._depthwise_conv", 1, b.mid, b.k, b.stride, b.pb, stage, false, P + "._bn1", false, be, bm);
+        m->convs[b.cdw].dw = true;
         b.cr = add_conv(m, P + "._se_reduce", b.mid, b.nsq, 1, 1, 0, stage, false, "", true);
         b.cx = add_conv(m, P + "._se_expand", b.nsq, b.mid, 1, 1, 0, stage, false, "", true);
         b.cp = add_conv(m, P + "._project_conv", b.mid, b.Cout, 1, 1, 0, stage, true, P + "._bn2", false, be, bm);
@@ -265,7 +268,7 @@ static int build_model(uwm_model* m) {
   for (int st = 0; st < 5; ++st) {
     m->stage_begin[st] = off;
     for (auto& c : m->convs) if (c.stage == st) {
-      c.w_off = off; off += (long long)c.Cout * c.Kpad;
+      c.w_off = off; off += c.wfloats();
       if (c.bias_off == 0) { c.bias_off = off; off += c.CoutP; }
     }
     for (auto& b : m->bns) if (b.stage == st) { b.g_off = off; off += b.C; b.b_off = off; off += b.C; }
@@ -296,6 +299,7 @@ static int build_model(uwm_model* m) {
   auto conv_info = [&](const ConvL& c) {
     long long shape[4] = {c.Cout, c.Cin, c.k, c.k};
     long long stride[4] = {c.Kpad, 1, (long long)c.k * c.CinP, c.CinP};
+    if (c.dw) { stride[0] = 1; stride[1] = 1; stride[2] = (long long)c.k * c.CoutP; stride[3] = c.CoutP; }
     push_info(m, c.name + ".weight", UWM_KIND_CONV_W, UWM_ARENA_PARAM, c.w_off, 4, shape, stride);
     m->param_count += (long long)c.Cout * c.Cin * c.k * c.k;
     if (c.bias_off >= 0) {
@@ -331,7 +335,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   p.y[m->stem] = alloc((size_t)N * h * w * stemC); p.oh[m->stem] = h; p.ow[m->stem] = w;
   size_t nblk = m->mb.size(); for (auto& s : m->stages) nblk += s.size();
   p.xn.assign(nblk, 0); p.gx.assign(nblk, 0);
-  size_t bi = 0; size_t max_in = 0, max_mid = 0;
+  size_t bi = 0; size_t max_in = 0, max_mid = 0, max_nsq = 0;
   auto place = [&](int ci, int oh, int ow) { p.y[ci] = alloc((size_t)N * oh * ow * m->convs[ci].CoutP); p.oh[ci] = oh; p.ow[ci] = ow; };
   if (m->mb.empty()) {
     h /= 2; w /= 2;
@@ -367,7 +371,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       p.oh[b.cr] = p.ow[b.cr] = p.oh[b.cx] = p.ow[b.cx] = 1;
       p.xn[bi] = alloc((size_t)N * h * w * b.Cout);
       p.mh[bi] = h; p.mw[bi] = w;
-      max_mid = std::max(max_mid, (size_t)b.mid);
+      max_mid = std::max(max_mid, (size_t)b.mid); max_nsq = std::max(max_nsq, (size_t)rup(b.nsq, 4));
     }
   }
   for (size_t i = 0; i < m->dec.size(); ++i) {
@@ -411,7 +415,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
           if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].CoutP);
         p.gx[i] = alloc((size_t)N * p.mh[i] * p.mw[i] * b.Cout);
       }
-      p.se_g = alloc(2 * (size_t)N * max_mid);
+      p.se_g = alloc(2 * (size_t)N * (max_mid + max_nsq)); p.se_gn = (size_t)N * max_mid;
     }
     h = H / 32; w = W / 32;                       // deepest feature: the decoder loop below doubles from here
     p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
@@ -657,7 +661,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
       }
       const ConvL& dw = m->convs[b.cdw];
       const size_t npo = (size_t)N * ho * wo;
-      LCHK(launch_dw_fwd(dwin, m->params + dw.w_off, dw.Kpad, b.k, b.stride, b.pb, N, h, w, b.mid, ho, wo, c.F(p.y[b.cdw]), st));
+      LCHK(launch_dw_fwd(dwin, m->params + dw.w_off, b.k, b.stride, b.pb, N, h, w, b.mid, ho, wo, c.F(p.y[b.cdw]), st));
       if (training) {
         const BNL& b1 = m->bns[dw.bn];
         LCHK(launch_colstats(c.F(p.y[b.cdw]), npo, b.mid, c.D(b1.d_off) + 2 * b1.C, c.D(b1.d_off) + 3 * b1.C, st));
@@ -889,12 +893,12 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       LCHK(run_dgrad(c, b.cp, gO, ho, wo, ho, wo, gM, nullptr, nullptr, nullptr, nullptr));
       // squeeze-and-excitation: gs = sum_hw g*a1 ; FC backward ; g_a1 = g*s + gpool/hw, then through swish(bn1(.))
       float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
-      float* gs = c.F(p.se_g); float* gpool = gs + (size_t)N * b.mid;
+      float* gs = c.F(p.se_g); float* gpool = gs + p.se_gn; float* hid = gpool + p.se_gn; float* gz1 = hid + (size_t)N * rup(b.nsq, 4);
       HIPCHK(hipMemsetAsync(gs, 0, (size_t)N * b.mid * sizeof(float), st));
       LCHK(launch_se_reduce_hw(gM, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, 1.f, gs, st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_bwd(gs, sv, hpre, pool, m->params + cr.w_off, cr.Kpad, m->params + cx.w_off, cx.Kpad, N, b.mid, b.nsq,
-                            gpool, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
+                            gpool, hid, gz1, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
       bn_ss(b.cdw, &sc, &sf);
       LCHK(launch_swish_bwd(gM, c.F(p.y[b.cdw]), sc, sf, b.mid, N, (size_t)ho * wo, sv, gpool, gM, st));
       LCHK(run_bn_bwd(c, b.cdw, gM, gM, npo));
@@ -910,18 +914,18 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       {
         hipStream_t ws_ = st;
         if (c.wst && c.wst != st) { HIPCHK(hipEventRecord(m->ev_fork, st)); HIPCHK(hipStreamWaitEvent(c.wst, m->ev_fork, 0)); ws_ = c.wst; }
-        LCHK(launch_dw_wgrad(dwin, gM, dw.Kpad, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, m->grads + dw.w_off, ws_));
+        LCHK(launch_dw_wgrad(dwin, gM, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, m->grads + dw.w_off, ws_));
       }
       if (b.ce >= 0) {
         float* gI = c.F(p.g[b.ce]);
-        LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, dw.Kpad, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, nullptr, gI, st));
+        LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, nullptr, gI, st));
         bn_ss(b.ce, &sc, &sf);
         LCHK(launch_swish_bwd(gI, c.F(p.y[b.ce]), sc, sf, b.mid, N, (size_t)hi * wi, nullptr, nullptr, gI, st));
         LCHK(run_bn_bwd(c, b.ce, gI, gI, npi));
         LCHK(run_wgrad(c, b.ce, in, nullptr, gI, hi, wi));
         LCHK(run_dgrad(c, b.ce, gI, hi, wi, hi, wi, gin, addend, nullptr, nullptr, nullptr));
       } else {
-        LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, dw.Kpad, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, addend, gin, st));
+        LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, addend, gin, st));
       }
     }
     if (s == 0) {
