@@ -327,9 +327,118 @@ hipError_t launch_colstats(const float* y, size_t npix, int C, double* ssum, dou
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- BatchNorm backward behind a swish (and the SE product)
+// The gradient that reaches a BatchNorm output through swish [and the squeeze-and-excitation product] is
+//   g' = (SE ? g * s[n][c] + gpool[n][c] / hw : g) * swish'(y*scale + shift)
+// Both BatchNorm-backward passes read g and y anyway, so g' is formed on the fly in each instead of in a pass of its own
+// (saves one read and one write of g and one read of y per MBConv stage).  Same reduction / apply structure as
+// bn_bwd_reduce_kernel / bn_bwd_apply_kernel (elementwise.hip).
+template <bool SE>
+__device__ __forceinline__ f4 act_grad(f4 gv, f4 yv, f4 sc, f4 sf, const float* se_s, const float* gpool, float inv_hw, size_t nc) {
+  if (SE) gv = gv * *(const f4*)(se_s + nc) + *(const f4*)(gpool + nc) * inv_hw;
+  return gv * dswish4(yv * sc + sf);
+}
+template <bool SE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_act_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ se_s,
+                                                                const float* __restrict__ gpool, float inv_hw, unsigned hw, double* dgamma,
+                                                                double* dbeta, size_t npix, int C, int CW) {
+  __shared__ float red[256 * 8];
+  const int c0 = blockIdx.y * CW;
+  const int tc = CW / 4, tr = 256 / tc;
+  const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
+  const int c = c0 + cx * 4;
+  f4 sg = {0, 0, 0, 0}, sgy = {0, 0, 0, 0};
+  if (rx < tr) {
+    const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), sc = *(const f4*)(scale + c), sf = *(const f4*)(shift + c);
+    const size_t ps = (size_t)gridDim.x * tr;
+    size_t p = (size_t)blockIdx.x * tr + rx;
+    f4 s2 = {0, 0, 0, 0};
+    for (; p + ps < npix; p += 2 * ps) {
+      const f4 g0 = *(const f4*)(g + p * C + c), g1 = *(const f4*)(g + (p + ps) * C + c);
+      const f4 y0 = *(const f4*)(y + p * C + c), y1 = *(const f4*)(y + (p + ps) * C + c);
+      const f4 a0 = act_grad<SE>(g0, y0, sc, sf, se_s, gpool, inv_hw, SE ? (size_t)((unsigned)p / hw) * C + c : 0);
+      const f4 a1 = act_grad<SE>(g1, y1, sc, sf, se_s, gpool, inv_hw, SE ? (size_t)((unsigned)(p + ps) / hw) * C + c : 0);
+      sg += a0 + a1;
+      s2 += a0 * (y0 - mu) + a1 * (y1 - mu);
+    }
+    for (; p < npix; p += ps) {
+      const f4 yv = *(const f4*)(y + p * C + c);
+      const f4 a0 = act_grad<SE>(*(const f4*)(g + p * C + c), yv, sc, sf, se_s, gpool, inv_hw, SE ? (size_t)((unsigned)p / hw) * C + c : 0);
+      sg += a0; s2 += a0 * (yv - mu);
+    }
+    sgy = s2 * rs;
+  }
+  float* r = red + threadIdx.x * 8;
+  r[0] = sg.x; r[1] = sg.y; r[2] = sg.z; r[3] = sg.w; r[4] = sgy.x; r[5] = sgy.y; r[6] = sgy.z; r[7] = sgy.w;
+  __syncthreads();
+  for (int t = threadIdx.x; t < tc * 8; t += 256) {
+    const int q = t / 8, e = t % 8;
+    double acc = 0.0;
+    for (int k = 0; k < tr; ++k) acc += (double)red[(k * tc + q) * 8 + e];
+    if (e < 4) atomicAdd(dbeta + c0 + q * 4 + e, acc); else atomicAdd(dgamma + c0 + q * 4 + (e - 4), acc);
+  }
+}
+template <bool SE>
+__global__ void bn_bwd_apply_act_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ se_s, const float* __restrict__ gpool,
+                                        float inv_hw, size_t per_img4, const double* __restrict__ dgamma, const double* __restrict__ dbeta,
+                                        float* __restrict__ dy, float* gamma_grad, float* beta_grad, size_t n4, int C, float invM) {
+  if (blockIdx.x == 0 && gamma_grad)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { gamma_grad[c] = (float)dgamma[c]; beta_grad[c] = (float)dbeta[c]; }
+  const size_t stride = (size_t)gridDim.x * blockDim.x;       // a multiple of C/4: a thread stays on one channel quad
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)((i * 4) % (size_t)C);
+  const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), gm = *(const f4*)(gamma + c), sc = *(const f4*)(scale + c), sf = *(const f4*)(shift + c);
+  f4 dg, db;
+  dg.x = (float)dgamma[c] * invM; dg.y = (float)dgamma[c + 1] * invM; dg.z = (float)dgamma[c + 2] * invM; dg.w = (float)dgamma[c + 3] * invM;
+  db.x = (float)dbeta[c] * invM; db.y = (float)dbeta[c + 1] * invM; db.z = (float)dbeta[c + 2] * invM; db.w = (float)dbeta[c + 3] * invM;
+  const f4 A = gm * rs, B = -(gm * rs * rs * dg), K = -(A * db) - B * mu;
+  for (; i + stride < n4; i += 2 * stride) {
+    const f4 g0 = *(const f4*)(g + i * 4), g1 = *(const f4*)(g + (i + stride) * 4);
+    const f4 y0 = *(const f4*)(y + i * 4), y1 = *(const f4*)(y + (i + stride) * 4);
+    *(f4*)(dy + i * 4) = A * act_grad<SE>(g0, y0, sc, sf, se_s, gpool, inv_hw, SE ? (i / per_img4) * C + c : 0) + B * y0 + K;
+    *(f4*)(dy + (i + stride) * 4) = A * act_grad<SE>(g1, y1, sc, sf, se_s, gpool, inv_hw, SE ? ((i + stride) / per_img4) * C + c : 0) + B * y1 + K;
+  }
+  for (; i < n4; i += stride) {
+    const f4 yv = *(const f4*)(y + i * 4);
+    *(f4*)(dy + i * 4) = A * act_grad<SE>(*(const f4*)(g + i * 4), yv, sc, sf, se_s, gpool, inv_hw, SE ? (i / per_img4) * C + c : 0) + B * yv + K;
+  }
+}
+// BatchNorm backward of y -> swish (-> SE product): g = gradient wrt the swish output (SE: wrt the SE-scaled tensor)
+hipError_t launch_bn_bwd_act(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma, const float* scale,
+                             const float* shift, const float* se_s, const float* gpool, int N, size_t hw, double* dgamma, double* dbeta,
+                             float* dy, float* gamma_grad, float* beta_grad, int C, hipStream_t st) {
+  const size_t npix = (size_t)N * hw;
+  const int CW = pick_cw(C);
+  if (!CW || npix >= (1ull << 32)) return hipErrorInvalidValue;
+  const int tr = 256 / (CW / 4);
+  const float inv_hw = (float)(1.0 / (double)hw);
+  const dim3 gr(nb(npix, tr * 8), C / CW);
+  if (se_s) hipLaunchKernelGGL((bn_bwd_reduce_act_kernel<true>), gr, dim3(256), 0, st, g, y, mean, rstd, scale, shift, se_s, gpool, inv_hw, (unsigned)hw, dgamma, dbeta, npix, C, CW);
+  else hipLaunchKernelGGL((bn_bwd_reduce_act_kernel<false>), gr, dim3(256), 0, st, g, y, mean, rstd, scale, shift, se_s, gpool, inv_hw, (unsigned)hw, dgamma, dbeta, npix, C, CW);
+  const size_t n4 = npix * C / 4;
+  unsigned nbk = nb(n4, 256 * 4);
+  const unsigned q = (unsigned)(C / 4);
+  unsigned unit;                                   // smallest block count with (blocks*256) % q == 0
+  { unsigned a_ = q, b_ = 256; while (b_) { unsigned t = a_ % b_; a_ = b_; b_ = t; } unit = q / a_; }
+  nbk = ((nbk + unit - 1) / unit) * unit;
+  const size_t per_img4 = hw * (size_t)C / 4;
+  const float invM = (float)(1.0 / (double)npix);
+  if (se_s) hipLaunchKernelGGL((bn_bwd_apply_act_kernel<true>), dim3(nbk), dim3(256), 0, st, g, y, mean, rstd, gamma, scale, shift, se_s, gpool, inv_hw, per_img4, dgamma, dbeta, dy, gamma_grad, beta_grad, n4, C, invM);
+  else hipLaunchKernelGGL((bn_bwd_apply_act_kernel<false>), dim3(nbk), dim3(256), 0, st, g, y, mean, rstd, gamma, scale, shift, se_s, gpool, inv_hw, per_img4, dgamma, dbeta, dy, gamma_grad, beta_grad, n4, C, invM);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- squeeze-and-excitation
-// mode 0: out[n][c] = mean over hw of a[n][hw][c] ; mode 1: out[n][c] = sum over hw of a * b
-__global__ __launch_bounds__(256) void se_reduce_hw_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t hw, int C, int CW,
+// out[n][c] += scale * sum over hw of v,  v = a * b (b given: the SE backward's sum g*a1), v = a (plain pooling), or
+// v = swish(a*sc + sh) which is ALSO written to act_out (the forward: the activation pass and the squeeze pooling are one
+// pass over the tensor).  out zeroed by the caller.
+__global__ __launch_bounds__(256) void se_reduce_hw_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh, float* __restrict__ act_out, size_t hw, int C, int CW,
                                                            float scale, float* __restrict__ out) {
   __shared__ float red[256 * 4];
   const int n = blockIdx.y;
@@ -338,13 +447,26 @@ __global__ __launch_bounds__(256) void se_reduce_hw_kernel(const float* __restri
   const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
   const int c = c0 + cx * 4;
   f4 acc = {0, 0, 0, 0};
-  if (rx < tr)
-    for (size_t p = (size_t)blockIdx.x * tr + rx; p < hw; p += (size_t)gridDim.x * tr) {
+  if (rx < tr) {
+    f4 scv = {1, 1, 1, 1}, shv = {0, 0, 0, 0};
+    if (sc) { scv = *(const f4*)(sc + c); shv = *(const f4*)(sh + c); }
+    const size_t ps = (size_t)gridDim.x * tr;
+    size_t p = (size_t)blockIdx.x * tr + rx;
+    for (; p + ps < hw; p += 2 * ps) {
+      const size_t o0 = ((size_t)n * hw + p) * C + c, o1 = ((size_t)n * hw + p + ps) * C + c;
+      f4 v0 = *(const f4*)(a + o0), v1 = *(const f4*)(a + o1);
+      if (b) { v0 = v0 * *(const f4*)(b + o0); v1 = v1 * *(const f4*)(b + o1); }
+      if (sc) { v0 = swish4(v0 * scv + shv); v1 = swish4(v1 * scv + shv); *(f4*)(act_out + o0) = v0; *(f4*)(act_out + o1) = v1; }
+      acc += v0 + v1;
+    }
+    for (; p < hw; p += ps) {
       const size_t o = ((size_t)n * hw + p) * C + c;
       f4 v = *(const f4*)(a + o);
       if (b) v = v * *(const f4*)(b + o);
+      if (sc) { v = swish4(v * scv + shv); *(f4*)(act_out + o) = v; }
       acc += v;
     }
+  }
   float* r = red + threadIdx.x * 4;
   r[0] = acc.x; r[1] = acc.y; r[2] = acc.z; r[3] = acc.w;
   __syncthreads();
@@ -355,15 +477,24 @@ __global__ __launch_bounds__(256) void se_reduce_hw_kernel(const float* __restri
     atomicAdd(out + (size_t)n * C + c0 + q * 4 + e, sum * scale);
   }
 }
-// out must be zeroed by the caller
-hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, hipStream_t st) {
+static hipError_t se_reduce_launch(const float* a, const float* b, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C,
+                                   float scale, float* out, hipStream_t st) {
   const int CW = pick_cw(C);
   if (!CW) return hipErrorInvalidValue;
   const int tr = 256 / (CW / 4);
-  unsigned bx = (unsigned)((hw + (size_t)tr * 32 - 1) / ((size_t)tr * 32));
-  if (bx > 64) bx = 64; if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(se_reduce_hw_kernel, dim3(bx, N, C / CW), dim3(256), 0, st, a, b, hw, C, CW, scale, out);
+  unsigned bx = (unsigned)((hw + (size_t)tr * 16 - 1) / ((size_t)tr * 16));
+  const unsigned cap = std::max(1u, 2048u / (unsigned)(N * (C / CW)));
+  if (bx > cap) bx = cap; if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(se_reduce_hw_kernel, dim3(bx, N, C / CW), dim3(256), 0, st, a, b, sc, sh, act_out, hw, C, CW, scale, out);
   return hipGetLastError();
+}
+hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, hipStream_t st) {
+  return se_reduce_launch(a, b, nullptr, nullptr, nullptr, N, hw, C, scale, out, st);
+}
+// act_out = swish(y*sc + sh) and pool[n][c] += mean over hw of it, in one pass
+hipError_t launch_swish_pool(const float* y, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C, float* pool,
+                             hipStream_t st) {
+  return se_reduce_launch(y, nullptr, sc, sh, act_out, N, hw, C, (float)(1.0 / (double)hw), pool, st);
 }
 // SE FCs, forward.  grid (N, ceil(C/256)): every workgroup recomputes the nsq hidden units of its sample (a wave per
 // unit: lanes along the C inputs, coalesced row reads of W1 [nsq][K1pad], shuffle reduce), then one thread per output

@@ -163,9 +163,15 @@ hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, i
                            int Ho, int Wo, const float* addend, float* dx, hipStream_t st);
 hipError_t launch_dw_wgrad(const float* x, const float* dy, int k, int stride, int pb, int N, int H, int W, int C,
                            int Ho, int Wo, float* dw, hipStream_t st);
+// BatchNorm backward behind swish [and the SE product]: swish_bwd fused into both BatchNorm-backward passes
+hipError_t launch_bn_bwd_act(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma, const float* scale,
+                             const float* shift, const float* se_s, const float* gpool, int N, size_t hw, double* dgamma, double* dbeta,
+                             float* dy, float* gamma_grad, float* beta_grad, int C, hipStream_t st);
 hipError_t launch_colstats(const float* y, size_t npix, int C, double* ssum, double* ssq, hipStream_t st);
 // out[n][c] += scale * sum_hw a[n][hw][c] (* b[n][hw][c]); out zeroed by the caller
 hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, hipStream_t st);
+hipError_t launch_swish_pool(const float* y, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C, float* pool,
+                             hipStream_t st);
 hipError_t launch_se_fc_fwd(const float* pool, const float* w1, const float* b1, int K1pad, const float* w2, const float* b2,
                             int K2pad, int N, int C, int nsq, float* hpre, float* s, hipStream_t st);
 // gs [N][C] is overwritten (gz2); hid / gz1: scratch [N][nsq] each; parameter gradients are plain stores

@@ -544,6 +544,14 @@ static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, si
                              npix, b.C, c.st);
 }
 
+// BatchNorm backward of conv ci whose output went through swish [and the SE product]: g = grad wrt that activation
+static hipError_t run_bn_bwd_act(const Ctx& c, int ci, const float* g, float* dy, int N, size_t hw, const float* se_s, const float* gpool) {
+  uwm_model* m = c.m; const ConvL& cv = m->convs[ci]; const BNL& b = m->bns[cv.bn];
+  const float* f = c.F(b.f_off);
+  return launch_bn_bwd_act(g, c.F(m->plan.y[ci]), f, f + b.C, m->params + b.g_off, f + 2 * b.C, f + 3 * b.C, se_s, gpool, N, hw,
+                           c.D(b.d_off), c.D(b.d_off) + b.C, dy, m->grads + b.g_off, m->grads + b.b_off, b.C, c.st);
+}
+
 #define LCHK(expr)                                                                                     \
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("launch failed: %s at %s:%d (%s)",  \
        hipGetErrorString(e_), __FILE__, __LINE__, #expr); } while (0)
@@ -668,10 +676,9 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
         LCHK(run_bn_finalize(c, dw.bn, npo, 1));
       }
       bn_ss(b.cdw, &sc, &sf);
-      LCHK(launch_swish_fwd(c.F(p.y[b.cdw]), sc, sf, b.mid, c.F(p.a1[bi]), npo, st));
       float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
       HIPCHK(hipMemsetAsync(pool, 0, (size_t)N * b.mid * sizeof(float), st));
-      LCHK(launch_se_reduce_hw(c.F(p.a1[bi]), nullptr, N, (size_t)ho * wo, b.mid, (float)(1.0 / ((double)ho * wo)), pool, st));
+      LCHK(launch_swish_pool(c.F(p.y[b.cdw]), sc, sf, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, pool, st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_fwd(pool, m->params + cr.w_off, m->params + cr.bias_off, cr.Kpad, m->params + cx.w_off,
                             m->params + cx.bias_off, cx.Kpad, N, b.mid, b.nsq, hpre, sv, st));
@@ -899,9 +906,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_bwd(gs, sv, hpre, pool, m->params + cr.w_off, cr.Kpad, m->params + cx.w_off, cx.Kpad, N, b.mid, b.nsq,
                             gpool, hid, gz1, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
-      bn_ss(b.cdw, &sc, &sf);
-      LCHK(launch_swish_bwd(gM, c.F(p.y[b.cdw]), sc, sf, b.mid, N, (size_t)ho * wo, sv, gpool, gM, st));
-      LCHK(run_bn_bwd(c, b.cdw, gM, gM, npo));
+      LCHK(run_bn_bwd_act(c, b.cdw, gM, gM, N, (size_t)ho * wo, sv, gpool));
       // block input and where its gradient goes
       Src in = bi == 0 ? f1 : mk_src(c.F(p.xn[bi - 1]), b.Cin, hi, wi);
       float* gin = bi == 0 ? c.F(p.g[m->stem]) : c.F(p.gx[bi - 1]);
@@ -919,9 +924,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       if (b.ce >= 0) {
         float* gI = c.F(p.g[b.ce]);
         LCHK(launch_dw_dgrad(gM, m->params + dw.w_off, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, nullptr, gI, st));
-        bn_ss(b.ce, &sc, &sf);
-        LCHK(launch_swish_bwd(gI, c.F(p.y[b.ce]), sc, sf, b.mid, N, (size_t)hi * wi, nullptr, nullptr, gI, st));
-        LCHK(run_bn_bwd(c, b.ce, gI, gI, npi));
+        LCHK(run_bn_bwd_act(c, b.ce, gI, gI, N, (size_t)hi * wi, nullptr, nullptr));
         LCHK(run_wgrad(c, b.ce, in, nullptr, gI, hi, wi));
         LCHK(run_dgrad(c, b.ce, gI, hi, wi, hi, wi, gin, addend, nullptr, nullptr, nullptr));
       } else {
@@ -930,9 +933,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     }
     if (s == 0) {
       float* g = c.F(p.g[m->stem]);
-      bn_ss(m->stem, &sc, &sf);
-      LCHK(launch_swish_bwd(g, c.F(p.y[m->stem]), sc, sf, m->f1C, N, (size_t)h1 * w1, nullptr, nullptr, g, st));
-      LCHK(run_bn_bwd(c, m->stem, g, g, (size_t)N * h1 * w1));
+      LCHK(run_bn_bwd_act(c, m->stem, g, g, N, (size_t)h1 * w1, nullptr, nullptr));
       Src x4 = mk_src(c.F(p.x4), m->CinP, H, W);
       LCHK(run_wgrad(c, m->stem, x4, nullptr, g, h1, w1));
     }
