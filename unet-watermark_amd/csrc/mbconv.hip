@@ -8,6 +8,7 @@
 // (/root/reference/src/models/unet_model.py:64-71 with ENCODER_NAME efficientnet-b4).
 #include "uwm_kernels.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace uwm {
 
@@ -65,8 +66,8 @@ hipError_t launch_swish_bwd(const float* g, const float* y, const float* sc, con
 // (the end pad is implied by Ho / Wo).  HBM-bound: a thread owns (channel quad, output column), keeps its k*k*4 weights
 // in registers and walks down the image in bands of TH output rows, so every input element is loaded ~(TH*S+K-S)/(TH*S)
 // times per column tap instead of K times; lanes run along (column, channel) = contiguous memory.
-template <int K, int S, int TH>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int flip, int pb, int H, int W,
+template <int K, int S, int TH, int MINB>
+__global__ __launch_bounds__(256, MINB) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int flip, int pb, int H, int W,
                                                      int C, int Ho, int Wo, const float* __restrict__ addend, float* __restrict__ y) {
   const int C4 = C >> 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -122,30 +123,37 @@ static inline void dw_grid(int cols_c4, int nbands, int N, dim3* g) {
   unsigned gy = (unsigned)std::max(1, std::min(nbands, (int)(4096 / std::max(1u, gx * (unsigned)N))));
   *g = dim3(gx, gy, (unsigned)N);
 }
-template <int K, int S, int TH>
+template <int K, int S, int TH, int MINB = 1>
 static hipError_t dw_fwd_launch(const float* x, const float* w, int flip, int pb, int N, int H, int W, int C, int Ho, int Wo,
                                 const float* addend, float* y, hipStream_t st) {
   dim3 g; dw_grid(Wo * (C / 4), (Ho + TH - 1) / TH, N, &g);
-  hipLaunchKernelGGL((dw_fwd_kernel<K, S, TH>), g, dim3(256), 0, st, x, w, flip, pb, H, W, C, Ho, Wo, addend, y);
+  hipLaunchKernelGGL((dw_fwd_kernel<K, S, TH, MINB>), g, dim3(256), 0, st, x, w, flip, pb, H, W, C, Ho, Wo, addend, y);
   return hipGetLastError();
+}
+static int dw_variant() { static int v = -1; if (v < 0) { const char* e = getenv("UWM_DW_VARIANT"); v = e ? atoi(e) : 0; } return v; }
+template <int K, int S>
+static hipError_t dw_any(const float* x, const float* w, int flip, int pb, int N, int H, int W, int C, int Ho, int Wo, const float* addend,
+                         float* y, hipStream_t st) {
+  if (dw_variant() == 1) return dw_fwd_launch<K, S, 2, 1>(x, w, flip, pb, N, H, W, C, Ho, Wo, addend, y, st);
+  return dw_fwd_launch<K, S, 4, 1>(x, w, flip, pb, N, H, W, C, Ho, Wo, addend, y, st);
 }
 hipError_t launch_dw_fwd(const float* x, const float* w, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
                          float* y, hipStream_t st) {
   if (C & 3) return hipErrorInvalidValue;
-  if (k == 3 && stride == 1) return dw_fwd_launch<3, 1, 8>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
-  if (k == 3 && stride == 2) return dw_fwd_launch<3, 2, 4>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
-  if (k == 5 && stride == 1) return dw_fwd_launch<5, 1, 8>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
-  if (k == 5 && stride == 2) return dw_fwd_launch<5, 2, 4>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 3 && stride == 1) return dw_any<3, 1>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 5 && stride == 1) return dw_any<5, 1>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 3 && stride == 2) return dw_any<3, 2>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
+  if (k == 5 && stride == 2) return dw_any<5, 2>(x, w, 0, pb, N, H, W, C, Ho, Wo, nullptr, y, st);
   return hipErrorInvalidValue;
 }
 
 // stride-2 dgrad: dx[hi][wi] = sum over (r, s) with (hi + pb - r), (wi + pb - s) even of dy[(hi+pb-r)/2][(wi+pb-s)/2] * w[r][s].
 // A thread owns (channel quad, input column wi) and bands of TH = 8 dx rows; per band it visits the NQ dy rows that
 // touch the band; with hi0 even, r = j + E - 2q for dx row j and dy row q, E = K-1 + (pb & 1) (template PBODD).
-template <int K, int PBODD>
+template <int K, int PBODD, int TH>
 __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w, int pb, int H, int W, int C,
                                                           int Ho, int Wo, const float* __restrict__ addend, float* __restrict__ dx) {
-  constexpr int TH = 8, E = K - 1 + PBODD, NQ = (TH - 1 + E) / 2 + 1;
+  constexpr int E = K - 1 + PBODD, NQ = (TH - 1 + E) / 2 + 1;
   const int C4 = C >> 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= W * C4) return;
@@ -193,40 +201,43 @@ hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, i
                            const float* addend, float* dx, hipStream_t st) {
   if (C & 3) return hipErrorInvalidValue;
   if (stride == 1) {                                 // correlation with the flipped filter, pad k-1-pb
-    if (k == 3) return dw_fwd_launch<3, 1, 8>(dy, w, 1, k - 1 - pb, N, Ho, Wo, C, H, W, addend, dx, st);
-    if (k == 5) return dw_fwd_launch<5, 1, 8>(dy, w, 1, k - 1 - pb, N, Ho, Wo, C, H, W, addend, dx, st);
+    if (k == 3) return dw_any<3, 1>(dy, w, 1, k - 1 - pb, N, Ho, Wo, C, H, W, addend, dx, st);
+    if (k == 5) return dw_any<5, 1>(dy, w, 1, k - 1 - pb, N, Ho, Wo, C, H, W, addend, dx, st);
     return hipErrorInvalidValue;
   }
   if (stride != 2 || (k != 3 && k != 5)) return hipErrorInvalidValue;
-  dim3 g; dw_grid(W * (C / 4), (H + 7) / 8, N, &g);
-  if (k == 3 && !(pb & 1)) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3, 0>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
-  else if (k == 3) hipLaunchKernelGGL((dw_dgrad_s2_kernel<3, 1>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
-  else if (!(pb & 1)) hipLaunchKernelGGL((dw_dgrad_s2_kernel<5, 0>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
-  else hipLaunchKernelGGL((dw_dgrad_s2_kernel<5, 1>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx);
+  const int th = dw_variant() == 1 ? 4 : 8;
+  dim3 g; dw_grid(W * (C / 4), (H + th - 1) / th, N, &g);
+#define DW_S2(KK, PO, TT) hipLaunchKernelGGL((dw_dgrad_s2_kernel<KK, PO, TT>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx)
+  if (th == 8) {
+    if (k == 3 && !(pb & 1)) DW_S2(3, 0, 8); else if (k == 3) DW_S2(3, 1, 8); else if (!(pb & 1)) DW_S2(5, 0, 8); else DW_S2(5, 1, 8);
+  } else {
+    if (k == 3 && !(pb & 1)) DW_S2(3, 0, 4); else if (k == 3) DW_S2(3, 1, 4); else if (!(pb & 1)) DW_S2(5, 0, 4); else DW_S2(5, 1, 4);
+  }
+#undef DW_S2
   return hipGetLastError();
 }
 
-// dw[tap][c] += sum over output pixels dy[pix][c] * x[pix*S - pb + tap][c].  Same walk as the forward kernel (thread =
-// channel quad x output column, bands of TH rows) with the k*k*4 partial sums in registers; at the end the partials of
-// the workgroup's threads that share a channel are combined in LDS (ds_add_f32) when the workgroup covers each channel
-// more than once (C/4 < 256), then one global atomic per (tap, channel) and workgroup.
+// dw[tap][c] += sum over output pixels dy[pix][c] * x[pix*S - pb + tap][c].  Same walk as the forward kernel with the
+// k*k*4 partial sums in registers.  A workgroup is CQ channel quads x (256 / CQ) output columns (CQ <= 32 divides C/4:
+// every pixel still gives CQ*16 contiguous bytes) and a share of the row bands; its columns are combined in LDS
+// (ds_add_f32 into [k*k][CQ*4] floats) before ONE global atomic per (tap, channel) and workgroup.
 template <int K, int S, int TH>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int pb, int H, int W, int C,
-                                                       int Ho, int Wo, int use_lds, float* __restrict__ dw) {
-  extern __shared__ float red[];                     // [K*K][C] when use_lds
-  const int C4 = C >> 2;
-  if (use_lds) {
-    for (int i = threadIdx.x; i < K * K * C; i += 256) red[i] = 0.f;
-    __syncthreads();
-  }
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const bool live = idx < Wo * C4;
-  const int wo = live ? idx / C4 : 0, c = live ? (idx - wo * C4) * 4 : 0;
+                                                       int Ho, int Wo, int CQ, int ncb, float* __restrict__ dw) {
+  __shared__ float red[K * K * 128];
+  const int cpb = 256 / CQ;                          // columns per workgroup
+  for (int i = threadIdx.x; i < K * K * CQ * 4; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int cq = threadIdx.x % CQ, col = threadIdx.x / CQ;
+  const int cb = blockIdx.x / ncb, wb = blockIdx.x - cb * ncb;
+  const int wo = wb * cpb + col;
+  const int c = (cb * CQ + cq) * 4;
   const int n = blockIdx.z;
-  f4 acc[K * K];
+  if (col < cpb && wo < Wo) {
+    f4 acc[K * K];
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-  if (live) {
+    for (int t = 0; t < K * K; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
     const float* xn = x + (size_t)n * H * W * C + c;
     const float* gn = dy + (size_t)n * Ho * Wo * C + (size_t)wo * C + c;
     const int wi0 = wo * S - pb;
@@ -253,37 +264,29 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         }
       }
     }
-  }
-  if (use_lds) {
-    if (live) {
-#pragma unroll
-      for (int t = 0; t < K * K; ++t) {
-        float* d = red + t * C + c;
-        atomicAdd(d, acc[t].x); atomicAdd(d + 1, acc[t].y); atomicAdd(d + 2, acc[t].z); atomicAdd(d + 3, acc[t].w);
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * K * C; i += 256) { const float v = red[i]; if (v != 0.f) atomicAdd(dw + i, v); }
-  } else if (live) {
 #pragma unroll
     for (int t = 0; t < K * K; ++t) {
-      float* d = dw + (size_t)t * C + c;
+      float* d = red + (t * CQ + cq) * 4;
       atomicAdd(d, acc[t].x); atomicAdd(d + 1, acc[t].y); atomicAdd(d + 2, acc[t].z); atomicAdd(d + 3, acc[t].w);
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * K * CQ * 4; i += 256) {
+    const int t = i / (CQ * 4), e = i - t * (CQ * 4);
+    atomicAdd(dw + (size_t)t * C + cb * CQ * 4 + e, red[i]);
   }
 }
 template <int K, int S, int TH>
 static hipError_t dw_wgrad_launch(const float* x, const float* dy, int pb, int N, int H, int W, int C, int Ho, int Wo, float* dw,
                                   hipStream_t st) {
-  const int use_lds = (C / 4) < 256;
-  const size_t lds = use_lds ? (size_t)K * K * C * sizeof(float) : 0;
-  if (lds > 64 * 1024) {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_kernel<K, S, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); once = true; }
-  }
-  dim3 g; dw_grid(Wo * (C / 4), (Ho + TH - 1) / TH, N, &g);
-  g.y = std::max(1u, std::min(g.y, 1024u / std::max(1u, g.x * g.z)));     // fewer, longer workgroups: the tail is one atomic per (tap, channel)
-  hipLaunchKernelGGL((dw_wgrad_kernel<K, S, TH>), g, dim3(256), lds, st, x, dy, pb, H, W, C, Ho, Wo, use_lds, dw);
+  const int C4 = C / 4;
+  int CQ = 1;
+  for (int d = 1; d <= 32 && d <= C4; ++d) if (C4 % d == 0) CQ = d;
+  const int cpb = 256 / CQ, ncb = (Wo + cpb - 1) / cpb;
+  const unsigned gx = (unsigned)((C4 / CQ) * ncb);
+  const int nbands = (Ho + TH - 1) / TH;
+  const unsigned gy = (unsigned)std::max(1, std::min(nbands, (int)(2048 / std::max(1u, gx * (unsigned)N))));
+  hipLaunchKernelGGL((dw_wgrad_kernel<K, S, TH>), dim3(gx, gy, (unsigned)N), dim3(256), 0, st, x, dy, pb, H, W, C, Ho, Wo, CQ, ncb, dw);
   return hipGetLastError();
 }
 hipError_t launch_dw_wgrad(const float* x, const float* dy, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
@@ -496,28 +499,27 @@ hipError_t launch_swish_pool(const float* y, const float* sc, const float* sh, f
                              hipStream_t st) {
   return se_reduce_launch(y, nullptr, sc, sh, act_out, N, hw, C, (float)(1.0 / (double)hw), pool, st);
 }
-// SE FCs, forward.  grid (N, ceil(C/256)): every workgroup recomputes the nsq hidden units of its sample (a wave per
-// unit: lanes along the C inputs, coalesced row reads of W1 [nsq][K1pad], shuffle reduce), then one thread per output
-// channel of its 256-channel slice (row of W2 [C][K2pad], 16-byte loads).  hid = swish(W1 pool + b1) (pre-activation
-// kept in hpre), s = sigmoid(W2 hid + b2).
-__global__ __launch_bounds__(256) void se_fc_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        int K1pad, const float* __restrict__ w2, const float* __restrict__ b2, int K2pad,
-                                                        int C, int nsq, float* __restrict__ hpre, float* __restrict__ s) {
-  extern __shared__ float sh[];        // [rup(nsq,4)] hidden (post-swish), zero padded
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int nsqP = (nsq + 3) & ~3;
+// SE FCs, forward, two small launches.  (1) grid (N, ceil(nsq/4)): a wave per hidden unit, lanes along the C inputs
+// (coalesced row of W1 [nsq][K1pad]), shuffle reduce: hpre = W1 pool + b1 (kept for the backward), hid = swish(hpre).
+// (2) grid (N, ceil(C/256)): a thread per output channel (row of W2 [C][K2pad], 16-byte loads): s = sigmoid(W2 hid + b2).
+__global__ __launch_bounds__(256) void se_fc1_kernel(const float* __restrict__ pool, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     int K1pad, int C, int nsq, float* __restrict__ hpre, float* __restrict__ hid) {
+  const int n = blockIdx.x, lane = threadIdx.x & 63, j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j >= nsq) return;
   const float* p = pool + (size_t)n * C;
-  for (int j = wv; j < nsqP; j += 4) {
-    float acc = 0.f;
-    if (j < nsq) for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * K1pad + c] * p[c];
+  const float* row = w1 + (size_t)j * K1pad;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) acc += row[c] * p[c];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) {
-      float h = 0.f;
-      if (j < nsq) { acc += b1[j]; h = acc * sigm(acc); if (blockIdx.y == 0) hpre[(size_t)n * nsq + j] = acc; }
-      sh[j] = h;
-    }
-  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) { acc += b1[j]; hpre[(size_t)n * nsq + j] = acc; hid[(size_t)n * nsq + j] = acc * sigm(acc); }
+}
+__global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hid, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     int K2pad, int C, int nsq, float* __restrict__ s) {
+  extern __shared__ float sh[];        // [rup(nsq,4)] hidden, zero padded
+  const int n = blockIdx.x;
+  const int nsqP = (nsq + 3) & ~3;
+  for (int j = threadIdx.x; j < nsqP; j += 256) sh[j] = j < nsq ? hid[(size_t)n * nsq + j] : 0.f;
   __syncthreads();
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c < C) {
@@ -527,25 +529,27 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(const float* __restrict_
     s[(size_t)n * C + c] = sigm(acc);
   }
 }
+// hid: scratch [N][nsq]
 hipError_t launch_se_fc_fwd(const float* pool, const float* w1, const float* b1, int K1pad, const float* w2, const float* b2,
-                            int K2pad, int N, int C, int nsq, float* hpre, float* s, hipStream_t st) {
-  hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(N, (C + 255) / 256), dim3(256), ((nsq + 3) & ~3) * sizeof(float), st, pool, w1, b1, K1pad,
-                     w2, b2, K2pad, C, nsq, hpre, s);
+                            int K2pad, int N, int C, int nsq, float* hpre, float* hid, float* s, hipStream_t st) {
+  hipLaunchKernelGGL(se_fc1_kernel, dim3(N, (nsq + 3) / 4), dim3(256), 0, st, pool, w1, b1, K1pad, C, nsq, hpre, hid);
+  hipLaunchKernelGGL(se_fc2_kernel, dim3(N, (C + 255) / 256), dim3(256), ((nsq + 3) & ~3) * sizeof(float), st, hid, w2, b2, K2pad, C, nsq, s);
   return hipGetLastError();
 }
-// SE FCs, backward, two launches and no global atomics.  (A) per sample: gz2 = gs * s(1-s) (in place over gs),
-// hid = swish(hpre), gz1 = (W2^T gz2) * swish'(hpre) — the W2^T product walks W2 rows (thread per channel) and adds into
-// nsq LDS accumulators, each lane starting at a different unit so the ds_add_f32 of a wave hit different addresses.
-// (B) over all samples: gW2 = sum_n gz2 hid^T, gW1 = sum_n gz1 pool^T, gb2, gb1 (plain stores: the gradient arena is
-// zeroed per backward and nothing else writes these tensors) and gpool = W1^T gz1.
-__global__ __launch_bounds__(256) void se_fc_bwd_a_kernel(float* __restrict__ gs, const float* __restrict__ s, const float* __restrict__ hpre,
-                                                          const float* __restrict__ w2, int K2pad, int C, int nsq, float* __restrict__ hid,
-                                                          float* __restrict__ gz1) {
+// SE FCs, backward, two launches.  (A) grid (N, ceil(C/256)), a thread per channel: gz2 = gs * s(1-s) (in place over
+// gs); its row of W2 times gz2 is added into nsq LDS accumulators (each lane starts at a different unit, so the
+// ds_add_f32 of a wave hit different addresses), then one global atomic per unit and workgroup into acc1 [N][nsq]
+// (zeroed by the caller) = W2^T gz2.  (B) over all samples, with gz1 = acc1 * swish'(hpre) and hid = swish(hpre) formed
+// on the fly: gW2 = sum_n gz2 hid^T, gW1 = sum_n gz1 pool^T, gb2, gb1 (plain stores: the gradient arena is zeroed per
+// backward and nothing else writes these tensors) and gpool = W1^T gz1.
+__global__ __launch_bounds__(256) void se_fc_bwd_a_kernel(float* __restrict__ gs, const float* __restrict__ s, const float* __restrict__ w2, int K2pad,
+                                                          int C, int nsq, float* __restrict__ acc1) {
   extern __shared__ float sh[];        // [nsq] accumulators
   const int n = blockIdx.x;
   for (int j = threadIdx.x; j < nsq; j += 256) sh[j] = 0.f;
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c < C) {
     const float sv = s[(size_t)n * C + c];
     const float g = gs[(size_t)n * C + c] * sv * (1.f - sv);
     gs[(size_t)n * C + c] = g;
@@ -554,37 +558,37 @@ __global__ __launch_bounds__(256) void se_fc_bwd_a_kernel(float* __restrict__ gs
     for (int jj = 0; jj < nsq; ++jj) { atomicAdd(&sh[j], row[j] * g); if (++j == nsq) j = 0; }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < nsq; j += 256) {
-    const float z = hpre[(size_t)n * nsq + j];
-    hid[(size_t)n * nsq + j] = z * sigm(z);
-    gz1[(size_t)n * nsq + j] = sh[j] * dswish(z);
-  }
+  for (int j = threadIdx.x; j < nsq; j += 256) atomicAdd(acc1 + (size_t)n * nsq + j, sh[j]);
 }
-__global__ __launch_bounds__(256) void se_fc_bwd_b_kernel(const float* __restrict__ gz2, const float* __restrict__ hid, const float* __restrict__ gz1,
+__global__ __launch_bounds__(256) void se_fc_bwd_b_kernel(const float* __restrict__ gz2, const float* __restrict__ hpre, const float* __restrict__ acc1,
                                                           const float* __restrict__ pool, const float* __restrict__ w1, int K1pad, int K2pad,
                                                           int N, int C, int nsq, float* __restrict__ gpool, float* __restrict__ gw1,
                                                           float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < C * nsq) {
-    { const int c = i / nsq, j = i - c * nsq; float a = 0.f; for (int n = 0; n < N; ++n) a += gz2[(size_t)n * C + c] * hid[(size_t)n * nsq + j]; gw2[(size_t)c * K2pad + j] = a; }
-    { const int j = i / C, c = i - j * C; float a = 0.f; for (int n = 0; n < N; ++n) a += gz1[(size_t)n * nsq + j] * pool[(size_t)n * C + c]; gw1[(size_t)j * K1pad + c] = a; }
+    { const int c = i / nsq, j = i - c * nsq; float a = 0.f;
+      for (int n = 0; n < N; ++n) { const float z = hpre[(size_t)n * nsq + j]; a += gz2[(size_t)n * C + c] * (z * sigm(z)); }
+      gw2[(size_t)c * K2pad + j] = a; }
+    { const int j = i / C, c = i - j * C; float a = 0.f;
+      for (int n = 0; n < N; ++n) a += acc1[(size_t)n * nsq + j] * dswish(hpre[(size_t)n * nsq + j]) * pool[(size_t)n * C + c];
+      gw1[(size_t)j * K1pad + c] = a; }
   }
   if (i < C) { float a = 0.f; for (int n = 0; n < N; ++n) a += gz2[(size_t)n * C + i]; gb2[i] = a; }
-  if (i < nsq) { float a = 0.f; for (int n = 0; n < N; ++n) a += gz1[(size_t)n * nsq + i]; gb1[i] = a; }
+  if (i < nsq) { float a = 0.f; for (int n = 0; n < N; ++n) a += acc1[(size_t)n * nsq + i] * dswish(hpre[(size_t)n * nsq + i]); gb1[i] = a; }
   if (i < N * C) {
     const int n = i / C, c = i - n * C;
     float a = 0.f;
-    for (int j = 0; j < nsq; ++j) a += w1[(size_t)j * K1pad + c] * gz1[(size_t)n * nsq + j];
+    for (int j = 0; j < nsq; ++j) a += w1[(size_t)j * K1pad + c] * (acc1[(size_t)n * nsq + j] * dswish(hpre[(size_t)n * nsq + j]));
     gpool[i] = a;
   }
 }
-// gs [N][C] is overwritten with gz2; hid / gz1: scratch [N][nsq] each
+// gs [N][C] is overwritten with gz2; acc1: scratch [N][nsq], zeroed by the caller
 hipError_t launch_se_fc_bwd(float* gs, const float* s, const float* hpre, const float* pool, const float* w1, int K1pad,
-                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* hid, float* gz1, float* gw1,
+                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* acc1, float* gw1,
                             float* gb1, float* gw2, float* gb2, hipStream_t st) {
-  hipLaunchKernelGGL(se_fc_bwd_a_kernel, dim3(N), dim3(256), nsq * sizeof(float), st, gs, s, hpre, w2, K2pad, C, nsq, hid, gz1);
+  hipLaunchKernelGGL(se_fc_bwd_a_kernel, dim3(N, (C + 255) / 256), dim3(256), nsq * sizeof(float), st, gs, s, w2, K2pad, C, nsq, acc1);
   const int work = std::max(C * nsq, N * C);
-  hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3((work + 255) / 256), dim3(256), 0, st, gs, hid, gz1, pool, w1, K1pad, K2pad, N, C, nsq,
+  hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3((work + 255) / 256), dim3(256), 0, st, gs, hpre, acc1, pool, w1, K1pad, K2pad, N, C, nsq,
                      gpool, gw1, gb1, gw2, gb2);
   return hipGetLastError();
 }

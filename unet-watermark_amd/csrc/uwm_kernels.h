@@ -173,10 +173,10 @@ hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw,
 hipError_t launch_swish_pool(const float* y, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C, float* pool,
                              hipStream_t st);
 hipError_t launch_se_fc_fwd(const float* pool, const float* w1, const float* b1, int K1pad, const float* w2, const float* b2,
-                            int K2pad, int N, int C, int nsq, float* hpre, float* s, hipStream_t st);
-// gs [N][C] is overwritten (gz2); hid / gz1: scratch [N][nsq] each; parameter gradients are plain stores
+                            int K2pad, int N, int C, int nsq, float* hpre, float* hid /* scratch [N][nsq] */, float* s, hipStream_t st);
+// gs [N][C] is overwritten (gz2); acc1: scratch [N][nsq] zeroed by the caller; parameter gradients are plain stores
 hipError_t launch_se_fc_bwd(float* gs, const float* s, const float* hpre, const float* pool, const float* w1, int K1pad,
-                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* hid, float* gz1, float* gw1,
+                            const float* w2, int K2pad, int N, int C, int nsq, float* gpool, float* acc1, float* gw1,
                             float* gb1, float* gw2, float* gb2, hipStream_t st);
 hipError_t launch_se_scale(const float* a, const float* s, int N, size_t hw, int C, float* out, hipStream_t st);
 // out = (y*sc+sh) * rowscale[n] + id   (rowscale / id may be nullptr)

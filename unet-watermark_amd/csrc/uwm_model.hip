@@ -72,7 +72,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   size_t stem_a = 0;                // EfficientNet: materialised stem feature f1 = swish(bn(conv_stem))
   std::vector<size_t> a0, a1, a2, se;   // EfficientNet per block: swish(bn0(expand)), swish(bn1(dw)), SE-scaled, {pool[N][mid], s[N][mid], hpre[N][nsqP]}
   std::vector<int> mh, mw;          // EfficientNet per block: output height / width
-  size_t se_g = 0, se_gn = 0;       // EfficientNet: SE backward scratch {gs, gpool: se_gn floats each; hid, gz1: N*max nsq each}
+  size_t se_g = 0, se_gn = 0, se_gq = 0;   // EfficientNet: SE backward scratch {gs [N][mid] + acc1 [N][nsq] (contiguous, within se_gn + se_gq floats), gpool [se_gn]}
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
@@ -366,7 +366,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       if (b.ce >= 0) { place(b.ce, hi, wi); p.a0[bi] = alloc((size_t)N * hi * wi * b.mid); }
       place(b.cdw, h, w);
       p.a1[bi] = alloc((size_t)N * h * w * b.mid); p.a2[bi] = alloc((size_t)N * h * w * b.mid);
-      p.se[bi] = alloc((size_t)N * (2 * b.mid + (size_t)rup(b.nsq, 4)));
+      p.se[bi] = alloc((size_t)N * (2 * b.mid + 2 * (size_t)rup(b.nsq, 4)));
       place(b.cp, h, w);
       p.oh[b.cr] = p.ow[b.cr] = p.oh[b.cx] = p.ow[b.cx] = 1;
       p.xn[bi] = alloc((size_t)N * h * w * b.Cout);
@@ -415,7 +415,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
           if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].CoutP);
         p.gx[i] = alloc((size_t)N * p.mh[i] * p.mw[i] * b.Cout);
       }
-      p.se_g = alloc(2 * (size_t)N * (max_mid + max_nsq)); p.se_gn = (size_t)N * max_mid;
+      p.se_g = alloc(2 * (size_t)N * (max_mid + max_nsq)); p.se_gn = (size_t)N * max_mid; p.se_gq = (size_t)N * max_nsq;
     }
     h = H / 32; w = W / 32;                       // deepest feature: the decoder loop below doubles from here
     p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
@@ -681,7 +681,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
       LCHK(launch_swish_pool(c.F(p.y[b.cdw]), sc, sf, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, pool, st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_fwd(pool, m->params + cr.w_off, m->params + cr.bias_off, cr.Kpad, m->params + cx.w_off,
-                            m->params + cx.bias_off, cx.Kpad, N, b.mid, b.nsq, hpre, sv, st));
+                            m->params + cx.bias_off, cx.Kpad, N, b.mid, b.nsq, hpre, hpre + (size_t)N * rup(b.nsq, 4), sv, st));
       LCHK(launch_se_scale(c.F(p.a1[bi]), sv, N, (size_t)ho * wo, b.mid, c.F(p.a2[bi]), st));
       Src a2 = mk_src(c.F(p.a2[bi]), b.mid, ho, wo);
       if (conv_bn(b.cp, a2, nullptr, ho, wo)) return 1;
@@ -900,12 +900,12 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       LCHK(run_dgrad(c, b.cp, gO, ho, wo, ho, wo, gM, nullptr, nullptr, nullptr, nullptr));
       // squeeze-and-excitation: gs = sum_hw g*a1 ; FC backward ; g_a1 = g*s + gpool/hw, then through swish(bn1(.))
       float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
-      float* gs = c.F(p.se_g); float* gpool = gs + p.se_gn; float* hid = gpool + p.se_gn; float* gz1 = hid + (size_t)N * rup(b.nsq, 4);
-      HIPCHK(hipMemsetAsync(gs, 0, (size_t)N * b.mid * sizeof(float), st));
+      float* gs = c.F(p.se_g); float* acc1 = gs + (size_t)N * b.mid; float* gpool = gs + p.se_gn + p.se_gq;
+      HIPCHK(hipMemsetAsync(gs, 0, (size_t)N * (b.mid + b.nsq) * sizeof(float), st));
       LCHK(launch_se_reduce_hw(gM, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, 1.f, gs, st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_bwd(gs, sv, hpre, pool, m->params + cr.w_off, cr.Kpad, m->params + cx.w_off, cx.Kpad, N, b.mid, b.nsq,
-                            gpool, hid, gz1, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
+                            gpool, acc1, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
       LCHK(run_bn_bwd_act(c, b.cdw, gM, gM, N, (size_t)ho * wo, sv, gpool));
       // block input and where its gradient goes
       Src in = bi == 0 ? f1 : mk_src(c.F(p.xn[bi - 1]), b.Cin, hi, wi);
