@@ -217,8 +217,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.arch}-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
-                                   + (f"(BASELINE.json configs[{1 if world == 1 else 2}])" if args.arch == "Unet" else
-                                      "(not a BASELINE config: SURVEY 8 f3 widening)"),
+                                   + (f"(BASELINE.json configs[{1 if world == 1 else 2}])"
+                                      if (args.arch == "Unet" and args.encoder == "resnet34" and s == 512 and n == 16) else
+                                      "(the per-GPU workload of BASELINE.json configs[3]: SURVEY 8 a18)"
+                                      if (args.arch == "Unet" and args.encoder == "efficientnet-b4" and s == 1024 and n == 4) else
+                                      "(not a BASELINE config: SURVEY 8 f3 / a18 widening)"),
                        "global_batch": world * n, "image": [s, s], "parallelism": f"dp{world}",
                        "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if (world > 1 or force_ddp) else "none")},
             "loss": round(loss_val, 6),
