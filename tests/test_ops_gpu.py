@@ -134,6 +134,20 @@ def test_conv_shapes(cuda, shape):
     _conv_case(cuda, n, cin, cout, h, w, k, s, p)
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 24, 144, 16, 24),      # EfficientNet expand: K = 24 (padded to one 32-float chunk), Cout = 144
+    (1, 144, 24, 24, 40),      # project: Cout 24
+    (3, 48, 12, 8, 8),         # SE-sized channel counts, ragged M
+    (1, 272, 1632, 8, 16),     # deep expand
+    (1, 1632, 272, 8, 8),      # deep project conv: K = 1632
+])
+def test_conv1x1_shapes(cuda, shape):
+    """1x1 convs of the MBConv / Bottleneck blocks on the flattened implicit GEMM: plain and lazy sources, statistics."""
+    n, cin, cout, h, w = shape
+    _conv_case(cuda, n, cin, cout, h, w, 1, 1, 0)
+    _conv_case(cuda, n, cin, cout, h, w, 1, 1, 0, lazy=True, seed=2)
+
+
 def test_conv_lazy_bn_relu_prologue(cuda):
     # consumer-side BatchNorm-apply + ReLU (negative scales included) and zero padding AFTER it
     _conv_case(cuda, 2, 64, 64, 16, 16, 3, 1, 1, lazy=True)
@@ -176,6 +190,8 @@ def test_conv_upsample_concat(cuda):
     (3, 64, 32, 8, 16, 3, 1, 1),      # wgrad_patch<32>, one tile per image
     (1, 32, 16, 32, 48, 3, 1, 1),     # dgrad runs conv_patch16<32> (dy has 16 channels)
     (2, 16, 16, 16, 32, 3, 1, 1),     # dgrad runs conv_patch16<16>
+    (2, 24, 144, 16, 24, 1, 1, 0),    # 1x1 stride 1 (EfficientNet expand): dgrad through conv_1x1 (K = 144, 24 outputs)
+    (1, 144, 40, 8, 24, 1, 1, 0),     # 1x1 project: dgrad K = 40 (2.5 k-steps), 144 outputs, ragged M
 ])
 @pytest.mark.parametrize("force_igemm", [0, 1, 2, 3])
 def test_dgrad_and_wgrad(cuda, shape, force_igemm):
