@@ -343,7 +343,12 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
     else if (a.Cout <= 64) cfg = (tiles128 >= 512) ? 1 : 4;
     else {
       const long b0 = tiles128 * ((a.Cout + 127) / 128);
-      if (b0 >= 512) cfg = 0;
+      // 1x1 layers with channel counts like 144 or 192 (MBConv expand / project dgrad): the 128-wide tile pads them to 256;
+      // the 64-wide tile wastes far fewer MFMAs and LDS reads
+      static const bool narrow = getenv("UWM_NO_NARROW_1X1") == nullptr;
+      const int pad128 = ((a.Cout + 127) / 128) * 128, pad64 = ((a.Cout + 63) / 64) * 64;
+      if (narrow && a.ntaps == 1 && pad128 * 100 > pad64 * 115 && tiles128 * (pad64 / 64) >= 512) cfg = 1;
+      else if (b0 >= 512) cfg = 0;
       else if (tiles128 * ((a.Cout + 63) / 64) >= 512) cfg = 1;
       else cfg = 4;
     }

@@ -218,13 +218,16 @@ hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, i
   return hipGetLastError();
 }
 
-// dw[tap][c] += sum over output pixels dy[pix][c] * x[pix*S - pb + tap][c].  Same walk as the forward kernel with the
-// k*k*4 partial sums in registers.  A workgroup is CQ channel quads x (256 / CQ) output columns (CQ <= 32 divides C/4:
-// every pixel still gives CQ*16 contiguous bytes) and a share of the row bands; its columns are combined in LDS
-// (ds_add_f32 into [k*k][CQ*4] floats) before ONE global atomic per (tap, channel) and workgroup.
+// dw[tap][c] += sum over output pixels dy[pix][c] * x[pix*S - pb + tap][c], two launches.
+// (1) same walk as the forward kernel with the k*k*4 partial sums in registers.  A workgroup is CQ channel quads x
+// (256 / CQ) output columns (CQ <= 32 divides C/4: every pixel still gives CQ*16 contiguous bytes) and a share of the row
+// bands; its columns are combined in LDS (ds_add_f32 into [k*k][CQ*4] floats) and stored as ONE partial
+// part[(column block, band share, image)][tap][c].  (2) a thread per (tap, channel) and share of the partials adds them
+// (coalesced along c) and issues one atomic into dw.  (Global float atomics from every workgroup — 6 M per launch on the 960-channel layers — took 4x the time of
+// the data pass itself.)
 template <int K, int S, int TH>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int pb, int H, int W, int C,
-                                                       int Ho, int Wo, int CQ, int ncb, float* __restrict__ dw) {
+                                                       int Ho, int Wo, int CQ, int ncb, float* __restrict__ part) {
   __shared__ float red[K * K * 128];
   const int cpb = 256 / CQ;                          // columns per workgroup
   for (int i = threadIdx.x; i < K * K * CQ * 4; i += 256) red[i] = 0.f;
@@ -271,31 +274,56 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     }
   }
   __syncthreads();
+  float* dst = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * ncb + wb) * (K * K) * C + cb * CQ * 4;
   for (int i = threadIdx.x; i < K * K * CQ * 4; i += 256) {
     const int t = i / (CQ * 4), e = i - t * (CQ * 4);
-    atomicAdd(dw + (size_t)t * C + cb * CQ * 4 + e, red[i]);
+    dst[(size_t)t * C + e] = red[i];
   }
 }
+__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;          // blockIdx.y: a share of the partials
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int p = p0;
+  for (; p + 3 < p1; p += 4) {
+    a0 += part[(size_t)p * n + i]; a1 += part[(size_t)(p + 1) * n + i]; a2 += part[(size_t)(p + 2) * n + i]; a3 += part[(size_t)(p + 3) * n + i];
+  }
+  for (; p < p1; ++p) a0 += part[(size_t)p * n + i];
+  if (p1 > p0) atomicAdd(dw + i, (a0 + a1) + (a2 + a3));
+}
+struct DwWgradCfg { int CQ, ncb; unsigned gx, gy; size_t parts; };
+template <int TH>
+static DwWgradCfg dw_wgrad_cfg(int N, int C, int Ho, int Wo) {
+  DwWgradCfg g; const int C4 = C / 4;
+  g.CQ = 1;
+  for (int d = 1; d <= 32 && d <= C4; ++d) if (C4 % d == 0) g.CQ = d;
+  const int cpb = 256 / g.CQ; g.ncb = (Wo + cpb - 1) / cpb;
+  g.gx = (unsigned)((C4 / g.CQ) * g.ncb);
+  const int nbands = (Ho + TH - 1) / TH;
+  g.gy = (unsigned)std::max(1, std::min(nbands, (int)(2048 / std::max(1u, g.gx * (unsigned)N))));
+  g.parts = (size_t)g.ncb * g.gy * N;
+  return g;
+}
+// scratch floats the two-stage depthwise weight gradient needs for this layer
+size_t dw_wgrad_scratch_floats(int k, int N, int C, int Ho, int Wo) { return dw_wgrad_cfg<4>(N, C, Ho, Wo).parts * (size_t)k * k * C; }
 template <int K, int S, int TH>
 static hipError_t dw_wgrad_launch(const float* x, const float* dy, int pb, int N, int H, int W, int C, int Ho, int Wo, float* dw,
-                                  hipStream_t st) {
-  const int C4 = C / 4;
-  int CQ = 1;
-  for (int d = 1; d <= 32 && d <= C4; ++d) if (C4 % d == 0) CQ = d;
-  const int cpb = 256 / CQ, ncb = (Wo + cpb - 1) / cpb;
-  const unsigned gx = (unsigned)((C4 / CQ) * ncb);
-  const int nbands = (Ho + TH - 1) / TH;
-  const unsigned gy = (unsigned)std::max(1, std::min(nbands, (int)(2048 / std::max(1u, gx * (unsigned)N))));
-  hipLaunchKernelGGL((dw_wgrad_kernel<K, S, TH>), dim3(gx, gy, (unsigned)N), dim3(256), 0, st, x, dy, pb, H, W, C, Ho, Wo, CQ, ncb, dw);
+                                  float* scratch, hipStream_t st) {
+  const DwWgradCfg g = dw_wgrad_cfg<TH>(N, C, Ho, Wo);
+  hipLaunchKernelGGL((dw_wgrad_kernel<K, S, TH>), dim3(g.gx, g.gy, (unsigned)N), dim3(256), 0, st, x, dy, pb, H, W, C, Ho, Wo, g.CQ, g.ncb, scratch);
+  const int n = K * K * C;
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((n + 255) / 256, (unsigned)std::max<size_t>(1, std::min<size_t>(16, g.parts / 8))), dim3(256), 0, st, scratch, (int)g.parts, n, dw);
   return hipGetLastError();
 }
 hipError_t launch_dw_wgrad(const float* x, const float* dy, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
-                           float* dw, hipStream_t st) {
-  if (C & 3) return hipErrorInvalidValue;
-  if (k == 3 && stride == 1) return dw_wgrad_launch<3, 1, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
-  if (k == 3 && stride == 2) return dw_wgrad_launch<3, 2, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
-  if (k == 5 && stride == 1) return dw_wgrad_launch<5, 1, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
-  if (k == 5 && stride == 2) return dw_wgrad_launch<5, 2, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, st);
+                           float* dw, float* scratch, hipStream_t st) {
+  if ((C & 3) || !scratch) return hipErrorInvalidValue;
+  if (k == 3 && stride == 1) return dw_wgrad_launch<3, 1, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, scratch, st);
+  if (k == 3 && stride == 2) return dw_wgrad_launch<3, 2, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, scratch, st);
+  if (k == 5 && stride == 1) return dw_wgrad_launch<5, 1, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, scratch, st);
+  if (k == 5 && stride == 2) return dw_wgrad_launch<5, 2, 4>(x, dy, pb, N, H, W, C, Ho, Wo, dw, scratch, st);
   return hipErrorInvalidValue;
 }
 

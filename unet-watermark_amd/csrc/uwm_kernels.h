@@ -161,8 +161,10 @@ hipError_t launch_dw_fwd(const float* x, const float* w, int k, int stride, int 
                          int Ho, int Wo, float* y, hipStream_t st);
 hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, int pb, int N, int H, int W, int C,
                            int Ho, int Wo, const float* addend, float* dx, hipStream_t st);
+// two-stage (partials + reduce, no global atomics): scratch holds dw_wgrad_scratch_floats(...) floats; dw += result
+size_t dw_wgrad_scratch_floats(int k, int N, int C, int Ho, int Wo);
 hipError_t launch_dw_wgrad(const float* x, const float* dy, int k, int stride, int pb, int N, int H, int W, int C,
-                           int Ho, int Wo, float* dw, hipStream_t st);
+                           int Ho, int Wo, float* dw, float* scratch, hipStream_t st);
 // BatchNorm backward behind swish [and the SE product]: swish_bwd fused into both BatchNorm-backward passes
 hipError_t launch_bn_bwd_act(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma, const float* scale,
                              const float* shift, const float* se_s, const float* gpool, int N, size_t hw, double* dgamma, double* dbeta,

@@ -72,6 +72,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   size_t stem_a = 0;                // EfficientNet: materialised stem feature f1 = swish(bn(conv_stem))
   std::vector<size_t> a0, a1, a2, se;   // EfficientNet per block: swish(bn0(expand)), swish(bn1(dw)), SE-scaled, {pool[N][mid], s[N][mid], hpre[N][nsqP]}
   std::vector<int> mh, mw;          // EfficientNet per block: output height / width
+  size_t dw_part = 0;               // EfficientNet: partial sums of the two-stage depthwise weight gradient (largest layer)
   size_t se_g = 0, se_gn = 0, se_gq = 0;   // EfficientNet: SE backward scratch {gs [N][mid] + acc1 [N][nsq] (contiguous, within se_gn + se_gq floats), gpool [se_gn]}
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
@@ -415,6 +416,9 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
           if (ci >= 0) p.g[ci] = alloc((size_t)N * p.oh[ci] * p.ow[ci] * m->convs[ci].CoutP);
         p.gx[i] = alloc((size_t)N * p.mh[i] * p.mw[i] * b.Cout);
       }
+      size_t max_part = 0;
+      for (size_t i = 0; i < m->mb.size(); ++i) max_part = std::max(max_part, dw_wgrad_scratch_floats(m->mb[i].k, N, m->mb[i].mid, p.mh[i], p.mw[i]));
+      p.dw_part = alloc(max_part);
       p.se_g = alloc(2 * (size_t)N * (max_mid + max_nsq)); p.se_gn = (size_t)N * max_mid; p.se_gq = (size_t)N * max_nsq;
     }
     h = H / 32; w = W / 32;                       // deepest feature: the decoder loop below doubles from here
@@ -919,7 +923,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       {
         hipStream_t ws_ = st;
         if (c.wst && c.wst != st) { HIPCHK(hipEventRecord(m->ev_fork, st)); HIPCHK(hipStreamWaitEvent(c.wst, m->ev_fork, 0)); ws_ = c.wst; }
-        LCHK(launch_dw_wgrad(dwin, gM, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, m->grads + dw.w_off, ws_));
+        LCHK(launch_dw_wgrad(dwin, gM, b.k, b.stride, b.pb, N, hi, wi, b.mid, ho, wo, m->grads + dw.w_off, c.F(p.dw_part), ws_));
       }
       if (b.ce >= 0) {
         float* gI = c.F(p.g[b.ce]);
