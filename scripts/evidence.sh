@@ -12,5 +12,7 @@ timeout -k 10 600 python bench.py > gpurun_out/${T}_bench_1gpu.json 2> gpurun_ou
 timeout -k 10 300 python bench_predict.py > gpurun_out/${T}_bench_predict.json 2>/dev/null; tail -c 400 gpurun_out/${T}_bench_predict.json
 timeout -k 10 400 python bench.py --arch UnetPlusPlus --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_bench_unetplusplus.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_unetplusplus.json
 timeout -k 10 400 python bench.py --encoder resnet50 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_bench_resnet50.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_resnet50.json
+timeout -k 10 400 python bench.py --encoder efficientnet-b4 --size 1024 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${T}_bench_effb4.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_effb4.json
+UWM_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace -d gpurun_out/${T}_effb4_trace -- python3 bench.py --encoder efficientnet-b4 --size 1024 --batch 4 --steps 4 --warmup 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_effb4_trace.log 2>&1; python scripts/rocpd_stats.py gpurun_out/${T}_effb4_trace/*/*.db 5 > gpurun_out/${T}_effb4_kernel_stats.txt; head -5 gpurun_out/${T}_effb4_kernel_stats.txt
 UWM_FORCE_DDP=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --serial-steps 0 > gpurun_out/${T}_bench_ddp_1rank.json 2>/dev/null; tail -c 200 gpurun_out/${T}_bench_ddp_1rank.json
 timeout -k 10 300 python scripts/logit_error.py resnet34 2 256 256 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_logit_error.txt; cat gpurun_out/${T}_logit_error.txt
