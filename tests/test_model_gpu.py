@@ -661,3 +661,29 @@ def test_efficientnet_b4_drop_connect_draw_and_trainer(cuda):
     tr = Trainer(m, w_dice=0.5, w_bce=0.5, smooth=1e-5, lr=1e-3)
     losses = [float(tr.step(x.to(cuda), t.to(cuda))[0]) for _ in range(12)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_cli_train_efficientnet_b4_checkpoint_and_predictor(cuda, tmp_path):
+    """`main.py train --encoder efficientnet-b4` (the README's config-4 encoder) end to end: the loss falls on the
+    synthetic set, the checkpoint carries the smp MBConv keys, and the hipGraph-replayed predictor (eval mode: no
+    drop-connect, running statistics) reproduces the eager forward bit for bit."""
+    from unet_watermark_amd import cli
+    hist = cli.main(["train", "--epochs", "3", "--batch-size", "4", "--lr", "0.002", "--no-early-stopping",
+                     "--synthetic", "32", "--img-size", "64", "--encoder", "efficientnet-b4", "--workers", "0",
+                     "--model-save-path", str(tmp_path / "eff.pth")])
+    assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
+    from unet_watermark_amd.checkpoint import load_checkpoint
+    ck = load_checkpoint(str(tmp_path / "eff.pth"))
+    sd = ck["model_state_dict"]
+    assert "encoder._blocks.31._project_conv.weight" in sd and sd["encoder._blocks.0._depthwise_conv.weight"].shape == (48, 1, 3, 3)
+    assert ck["config"]["MODEL"]["ENCODER_NAME"] == "efficientnet-b4"
+    import unet_watermark_amd as U
+    from unet_watermark_amd.predict import WatermarkPredictor
+    m = U.Unet("efficientnet-b4").to(cuda)
+    m.load_state_dict(sd)
+    pred = WatermarkPredictor(model=m, device=cuda)
+    img = torch.randint(0, 256, (2, 64, 64, 3), generator=torch.Generator().manual_seed(1), dtype=torch.uint8)
+    x = pred.preprocess(img)
+    a = pred.logits(x, use_graph=True).clone()
+    b = pred.logits(x, use_graph=False)
+    assert torch.isfinite(a).all() and (a - b).abs().max() < 1e-5      # (the SE pooling sums with float atomics: not bitwise)
