@@ -488,11 +488,16 @@ def test_bench_ddp_path_single_rank_rccl(cuda):
     ("UnetPlusPlus", "resnet18", 5, 96, 160, True),    # odd feature maps: fused concat split and dcat fallback mixed
     ("UnetPlusPlus", "resnet34", 1, 224, 224, True),
     ("Unet", "resnet50", 3, 96, 160, True),
+    ("Unet", "efficientnet-b4", 1, 32, 32, False),      # deepest MBConv stages on 1x1 pixels: every 5x5 depthwise tap but one is padding
+    ("Unet", "efficientnet-b4", 3, 32, 64, False),
+    ("Unet", "efficientnet-b4", 3, 96, 160, True),      # odd batch, 3x5 deepest map, ragged depthwise bands
+    ("UnetPlusPlus", "efficientnet-b4", 2, 64, 416, True),
 ])
 def test_shape_sweep_forward_and_gradient_direction(cuda, arch, enc, n, h, w, train):
     import unet_watermark_amd as U
     from oracle import unet_oracle as O
     m, ref = _pair(enc, dev=cuda, seed=5, arch=arch)
+    m.drop_connect = False                      # (EfficientNet: stochastic depth has its own parity test)
     x, t = O.synthetic_batch(n, h, w, seed=21)
     if not train:
         m.eval(); ref.eval()
@@ -503,6 +508,9 @@ def test_shape_sweep_forward_and_gradient_direction(cuda, arch, enc, n, h, w, tr
     out_ref = ref(x); O.DiceLoss(smooth=1e-5)(out_ref, t.unsqueeze(1)).backward()
     out = m(x.to(cuda)); U.DiceLoss(smooth=1e-5)(out, t.unsqueeze(1).to(cuda)).backward()
     assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    if enc == "efficientnet-b4":
+        _effb4_grad_check(m, ref, l2_rel=1e-1, cos_min=0.995)
+        return
     _grad_check(m, ref, l2_rel=(1e-1 if enc == "resnet50" else 6e-2), cos_min=(0.995 if enc == "resnet50" else 0.998))
 
 
