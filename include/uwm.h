@@ -148,6 +148,14 @@ int  uwm_set_winograd(int on);
  * draws it each step (uwm_mbconv_drop_rate gives p_block; blocks without identity skip ignore their row).  NULL (the
  * default) disables it.  The pointer is read by the next uwm_forward(training=1) and its uwm_backward. */
 int  uwm_set_drop_connect(uwm_handle h, const float* rowscale);
+/* Single-operator entry point of the depthwise k x k convolution (k 3|5, stride 1|2; tests and kernel timing).  NHWC
+ * activations, weights tap-major [k*k][C]; pad_begin = zero pad at the top/left (efficientnet_pytorch's static "same"
+ * padding: the bottom/right pad follows from Ho, Wo).  mode 0: out[N][Ho][Wo][C] = conv(a = x[N][H][W][C], b = w);
+ * mode 1: out[N][H][W][C] = dgrad(a = dy[N][Ho][Wo][C], b = w) (+ addend); mode 2: out[k*k][C] += wgrad(a = x, b = dy),
+ * scratch = uwm_op_depthwise_scratch_floats(...) floats. */
+int  uwm_op_depthwise(int mode, const float* a, const float* b, int k, int stride, int pad_begin, int N, int H, int W, int C,
+                      int Ho, int Wo, const float* addend, float* out, float* scratch, uwm_stream stream);
+long long uwm_op_depthwise_scratch_floats(int k, int N, int C, int Ho, int Wo);
 int  uwm_num_mbconv_blocks(uwm_handle h);
 float uwm_mbconv_drop_rate(uwm_handle h, int block);
 /* predict.py:620-625 on the device: bilinear resize (cv2.INTER_LINEAR convention) of each image's logit plane

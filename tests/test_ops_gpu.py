@@ -427,3 +427,46 @@ def test_residual_and_maxpool_backward(cuda):
     # positive near-ties may route to another tap on one side only (FMA rounding): tolerate a handful
     bad = ((gin.cpu() - refg).abs() > 1e-5).float().mean()
     assert bad < 1e-3, bad
+
+
+@pytest.mark.parametrize("shape", [
+    # n, c, h, w, k, stride, pad_begin (efficientnet_pytorch static same padding: (0,1) | (1,1) | (2,2) | (1,2))
+    (2, 48, 16, 24, 3, 1, 1),
+    (2, 144, 32, 32, 3, 2, 0),       # pad (0,1)
+    (1, 192, 24, 40, 5, 2, 2),       # pad (2,2), ragged bands (12 output rows, 20 columns)
+    (3, 960, 8, 8, 5, 2, 1),         # pad (1,2), 240 channel quads
+    (2, 336, 12, 20, 5, 1, 2),
+    (1, 24, 7, 9, 3, 1, 1),          # odd sizes, 6 channel quads
+    (1, 2688, 4, 4, 3, 1, 1),        # widest layer on a 4x4 map: almost every tap is padding
+])
+def test_depthwise_conv_forward_dgrad_wgrad(cuda, shape):
+    """mbconv.hip depthwise kernels (tap-major weights, asymmetric static padding) against torch's grouped conv2d and its
+    autograd: forward, dgrad (+ addend), wgrad (accumulating)."""
+    L = lib()
+    n, c, h, w, k, s, pb = shape
+    g = torch.Generator().manual_seed(11)
+    ho, wo = -(-h // s), -(-w // s)
+    pe_h = max((ho - 1) * s + k - h - pb, 0); pe_w = max((wo - 1) * s + k - w - pb, 0)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(c, 1, k, k, generator=g) * 0.2).requires_grad_()
+    y = F.conv2d(F.pad(x, (pb, pe_w, pb, pe_h)), wt, None, s, 0, groups=c)
+    assert y.shape[-2:] == (ho, wo)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd, dyd = nhwc(x.detach()).to(cuda), nhwc(dy).to(cuda)
+    wd = wt.detach().reshape(c, k * k).t().contiguous().to(cuda)           # [k*k][C]
+    out = torch.full((n, ho, wo, c), float("nan"), device=cuda)
+    L.check(L.lib().uwm_op_depthwise(0, P(xd), P(wd), k, s, pb, n, h, w, c, ho, wo, None, P(out), None, stream()))
+    add = torch.randn(n, h, w, c, generator=g)
+    dx = torch.full((n, h, w, c), float("nan"), device=cuda)
+    L.check(L.lib().uwm_op_depthwise(1, P(dyd), P(wd), k, s, pb, n, h, w, c, ho, wo, P(add.to(cuda)), P(dx), None, stream()))
+    dw0 = torch.randn(k * k, c, generator=g)
+    dw = dw0.to(cuda)
+    scr = torch.empty(max(1, L.lib().uwm_op_depthwise_scratch_floats(k, n, c, ho, wo)), device=cuda)
+    L.check(L.lib().uwm_op_depthwise(2, P(xd), P(dyd), k, s, pb, n, h, w, c, ho, wo, None, P(dw), P(scr), stream()))
+    torch.cuda.synchronize()
+    assert (nchw(out.cpu(), c) - y.detach()).abs().max() < 2e-5 * max(1.0, float(y.abs().max()))
+    ref_dx = x.grad.permute(0, 2, 3, 1) + add
+    assert (dx.cpu() - ref_dx).abs().max() < 2e-5 * max(1.0, float(ref_dx.abs().max()))
+    ref_dw = wt.grad.reshape(c, k * k).t() + dw0
+    assert (dw.cpu() - ref_dw).abs().max() < 5e-5 * max(1.0, float(ref_dw.abs().max()))

@@ -70,6 +70,8 @@ SIGNATURES = {
     "uwm_set_winograd": (I, [I]),
     "uwm_set_join_stream": (I, [P, P]),
     "uwm_set_drop_connect": (I, [P, P]),
+    "uwm_op_depthwise": (I, [I, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P]),
+    "uwm_op_depthwise_scratch_floats": (L, [I, I, I, I, I]),
     "uwm_num_mbconv_blocks": (I, [P]),
     "uwm_mbconv_drop_rate": (F, [P, I]),
     "uwm_preprocess_u8": (I, [P, I, I, I, I, C.POINTER(C.c_float), C.POINTER(C.c_float), P, P, P]),

@@ -228,19 +228,18 @@ hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, i
 template <int K, int S, int TH>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int pb, int H, int W, int C,
                                                        int Ho, int Wo, int CQ, int ncb, float* __restrict__ part) {
-  __shared__ float red[K * K * 128];
+  constexpr int TG = K == 5 ? 5 : 9;                 // taps combined per round: [TG][256] 16-byte slots of LDS
+  __shared__ f4 buf[TG * 256];
   const int cpb = 256 / CQ;                          // columns per workgroup
-  for (int i = threadIdx.x; i < K * K * CQ * 4; i += 256) red[i] = 0.f;
-  __syncthreads();
   const int cq = threadIdx.x % CQ, col = threadIdx.x / CQ;
   const int cb = blockIdx.x / ncb, wb = blockIdx.x - cb * ncb;
   const int wo = wb * cpb + col;
   const int c = (cb * CQ + cq) * 4;
   const int n = blockIdx.z;
-  if (col < cpb && wo < Wo) {
-    f4 acc[K * K];
+  f4 acc[K * K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < K * K; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+  if (col < cpb && wo < Wo) {
     const float* xn = x + (size_t)n * H * W * C + c;
     const float* gn = dy + (size_t)n * Ho * Wo * C + (size_t)wo * C + c;
     const int wi0 = wo * S - pb;
@@ -267,17 +266,22 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
         }
       }
     }
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-      float* d = red + (t * CQ + cq) * 4;
-      atomicAdd(d, acc[t].x); atomicAdd(d + 1, acc[t].y); atomicAdd(d + 2, acc[t].z); atomicAdd(d + 3, acc[t].w);
-    }
   }
-  __syncthreads();
+  // combine the workgroup's columns: TG taps per round through LDS (plain stores, then CQ*TG threads add cpb slots each;
+  // LDS float atomics here cost a fixed ~270 us per 5x5 launch, whatever the tensor size)
   float* dst = part + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * ncb + wb) * (K * K) * C + cb * CQ * 4;
-  for (int i = threadIdx.x; i < K * K * CQ * 4; i += 256) {
-    const int t = i / (CQ * 4), e = i - t * (CQ * 4);
-    dst[(size_t)t * C + e] = red[i];
+#pragma unroll
+  for (int t0 = 0; t0 < K * K; t0 += TG) {
+    if (t0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TG; ++i) buf[i * 256 + threadIdx.x] = acc[t0 + i];       // (threads without a column hold zeros)
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TG * CQ; idx += 256) {
+      const int i = idx / CQ, q = idx - i * CQ;
+      f4 sum = buf[i * 256 + q];
+      for (int cl = 1; cl < cpb; ++cl) sum += buf[i * 256 + cl * CQ + q];
+      *(f4*)(dst + (size_t)(t0 + i) * C + q * 4) = sum;
+    }
   }
 }
 __global__ void dw_wgrad_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ dw) {

@@ -1254,6 +1254,18 @@ float uwm_mbconv_drop_rate(uwm_handle h, int block) {
   if (!h || block < 0 || block >= (int)h->mb.size()) return 0.f;
   return h->mb[block].skip ? h->mb[block].drop : 0.f;
 }
+int uwm_op_depthwise(int mode, const float* a, const float* b, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
+                     const float* addend, float* out, float* scratch, uwm_stream stream) {
+  if (!a || !b || !out || N < 1 || (C & 3) || (k != 3 && k != 5) || (stride != 1 && stride != 2)) return fail("uwm_op_depthwise: bad argument");
+  if (pb < 0 || pb >= k || Ho < 1 || Wo < 1 || (Ho - 1) * stride - pb >= H || (Wo - 1) * stride - pb >= W) return fail("uwm_op_depthwise: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) LCHK(launch_dw_fwd(a, b, k, stride, pb, N, H, W, C, Ho, Wo, out, st));
+  else if (mode == 1) LCHK(launch_dw_dgrad(a, b, k, stride, pb, N, H, W, C, Ho, Wo, addend, out, st));
+  else if (mode == 2) { if (!scratch) return fail("uwm_op_depthwise: wgrad needs scratch"); LCHK(launch_dw_wgrad(a, b, k, stride, pb, N, H, W, C, Ho, Wo, out, scratch, st)); }
+  else return fail("uwm_op_depthwise: bad mode %d", mode);
+  return 0;
+}
+long long uwm_op_depthwise_scratch_floats(int k, int N, int C, int Ho, int Wo) { return (long long)dw_wgrad_scratch_floats(k, N, C, Ho, Wo); }
 int uwm_set_winograd(int on) { winograd_set_mode(on < 0 ? 0 : (on > 2 ? 1 : on)); return 0; }
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }
 
