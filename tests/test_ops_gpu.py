@@ -192,6 +192,11 @@ def test_conv_upsample_concat(cuda):
     (2, 16, 16, 16, 32, 3, 1, 1),     # dgrad runs conv_patch16<16>
     (2, 24, 144, 16, 24, 1, 1, 0),    # 1x1 stride 1 (EfficientNet expand): dgrad through conv_1x1 (K = 144, 24 outputs)
     (1, 144, 40, 8, 24, 1, 1, 0),     # 1x1 project: dgrad K = 40 (2.5 k-steps), 144 outputs, ragged M
+    (2, 56, 336, 8, 16, 1, 1, 0),     # 1x1 expand with Kpad = 64: wgrad on the 128x64 tile (Kpad = 32 above: 128x32)
+    (1, 160, 192, 8, 8, 1, 1, 0),     # Kpad = 160: three 64-column tiles instead of two 128-column ones
+    (2, 48, 24, 16, 16, 1, 1, 0),     # 1x1 project with 24 outputs, Kpad = 64: wgrad on the 32x64 tile
+    (1, 144, 32, 8, 24, 1, 1, 0),     # Kpad = 160 under 32 outputs: the 32x64 / 32x128 tiles
+    (1, 96, 24, 8, 8, 1, 1, 0),       # Kpad = 96
 ])
 @pytest.mark.parametrize("force_igemm", [0, 1, 2, 3])
 def test_dgrad_and_wgrad(cuda, shape, force_igemm):

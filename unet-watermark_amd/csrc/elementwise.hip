@@ -603,7 +603,8 @@ const char* prof_class_name(int cls) {
       "wgrad_patch_kernel<32>",         "wgrad_patch_kernel<64>",         "conv_patch16_kernel<16>",
       "conv_patch16_kernel<32>",        "conv_wino_kernel<64>",           "conv_wino_kernel<32>",
       "conv_wino_kernel<16>",           "wgrad_wino_kernel<64>",          "wgrad_wino_kernel<32>",
-      "wgrad_wino_kernel<16>",          "conv_wino8_kernel"};
+      "wgrad_wino_kernel<16>",          "conv_wino8_kernel",              "wgrad_igemm_kernel<128,32,2,2>",
+      "wgrad_igemm_kernel<128,64,2,2>",  "wgrad_igemm_kernel<32,64,2,2>",  "wgrad_igemm_kernel<32,128,1,4>"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

@@ -224,10 +224,27 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   WgradArgs a = a0;
   if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int TA, TB;
+  // 1x1 layers (MBConv expand / project, Bottleneck): the k extent is just the input channel count (Kpad 32..2688), so a
+  // narrower k tile is taken when it cuts the padded columns by >= 15 % (a 128-column tile on Kpad = 32 spends 3/4 of its
+  // MFMAs and LDS traffic on zeros)
+  static const bool narrow = getenv("UWM_NO_NARROW_WGRAD") == nullptr;
+  auto padded = [&](int tb) { return (a.Kpad + tb - 1) / tb * tb; };
   if (a.wrows <= 16) { TA = 16; TB = 256; }
-  else if (a.wrows <= 32) { TA = 32; TB = 256; }
+  else if (a.wrows <= 32) {
+    TA = 32; TB = 256;
+    if (narrow && a.ntaps == 1) {
+      if (padded(128) * 100 <= padded(TB) * 85) TB = 128;
+      if (padded(64) * 100 <= padded(TB) * 85) TB = 64;
+    }
+  }
   else if (a.wrows <= 64) { TA = 64; TB = 128; }
-  else { TA = 128; TB = 128; }
+  else {
+    TA = 128; TB = 128;
+    if (narrow && a.ntaps == 1) {
+      if (padded(64) * 100 <= padded(TB) * 85) TB = 64;
+      if (a.Kpad <= 96 && padded(32) * 100 <= padded(TB) * 85) TB = 32;
+    }
+  }
   const int tiles = ((a.wrows + TA - 1) / TA) * ((a.Kpad + TB - 1) / TB);
   // aim for ~1024 workgroups, at least 256 pixels (8 steps) per split
   int nsplit = (1024 + tiles - 1) / tiles;
@@ -240,9 +257,15 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   a.nsplit = nsplit; a.msplit = msplit;
   switch (TA) {
     case 16: return launch_w<16, 256, 1, 4>(a, st, 8);
-    case 32: return launch_w<32, 256, 1, 4>(a, st, 9);
+    case 32:
+      if (TB == 64) return launch_w<32, 64, 2, 2>(a, st, 28);
+      if (TB == 128) return launch_w<32, 128, 1, 4>(a, st, 29);
+      return launch_w<32, 256, 1, 4>(a, st, 9);
     case 64: return launch_w<64, 128, 2, 2>(a, st, 6);
-    default: return launch_w<128, 128, 2, 2>(a, st, 7);
+    default:
+      if (TB == 32) return launch_w<128, 32, 2, 2>(a, st, 26);
+      if (TB == 64) return launch_w<128, 64, 2, 2>(a, st, 27);
+      return launch_w<128, 128, 2, 2>(a, st, 7);
   }
 }
 
