@@ -14,7 +14,8 @@ LAYERS = [("exp2", 24, 144, 512, 1), ("exp3-5", 32, 192, 256, 3), ("exp6", 32, 1
           ("prj0", 48, 24, 512, 1), ("prj1", 24, 24, 512, 1), ("prj2", 144, 32, 256, 1), ("prj3-5", 192, 32, 256, 3), ("prj6", 192, 56, 128, 1),
           ("prj7-9", 336, 56, 128, 3), ("prj10", 336, 112, 64, 1), ("prj11-15", 672, 112, 64, 5), ("prj16", 672, 160, 64, 1),
           ("prj17-21", 960, 160, 64, 5), ("prj22", 960, 272, 32, 1), ("prj23-29", 1632, 272, 32, 7), ("prj30", 1632, 448, 32, 1), ("prj31", 2688, 448, 32, 1)]
-only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
+only = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] != "all" else None
+sweep = len(sys.argv) > 2 and sys.argv[2] == "sweep"          # forward conv on every implicit-GEMM tile config
 tot = [0.0, 0.0, 0.0]
 def timeit(f):
     for _ in range(2): f()
@@ -42,4 +43,10 @@ for name, cin, cout, h, cnt in LAYERS:
         us = timeit(f); tot[i] += us * cnt
         out.append(f"{us:7.1f} us {byt / us / 1e3:5.0f} GB/s {fl / us / 1e6:5.1f} TF")
     print(f"{name:9s} {cin:4d}->{cout:4d} {h:3d}^2 x{cnt}: fwd {out[0]} | dgrad {out[1]} | wgrad {out[2]}")
+    if sweep:
+        res = []
+        for cfg in (0, 1, 2, 4, 5):
+            f = lambda: L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(w), cout, kpad, 1, 1, 1, 0, N, cout, None, P(y), P(stats), cfg, stream()))
+            res.append(f"cfg{cfg} {timeit(f):6.1f}")
+        print("          fwd sweep: " + "  ".join(res))
 print(f"per step: fwd {tot[0] / 1e3:.2f} ms, dgrad {tot[1] / 1e3:.2f} ms, wgrad {tot[2] / 1e3:.2f} ms")
