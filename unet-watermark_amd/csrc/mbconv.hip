@@ -8,7 +8,6 @@
 // (/root/reference/src/models/unet_model.py:64-71 with ENCODER_NAME efficientnet-b4).
 #include "uwm_kernels.h"
 #include <algorithm>
-#include <cstdlib>
 
 namespace uwm {
 
@@ -36,30 +35,6 @@ hipError_t launch_swish_fwd(const float* y, const float* sc, const float* sh, in
   hipLaunchKernelGGL(swish_fwd_kernel, dim3(nb(n4, 256)), dim3(256), 0, st, y, sc, sh, C, out, n4);
   return hipGetLastError();
 }
-// out = g * swish'(y*scale + shift)  [ * optional extra: (g*s[n][c] + gpool[n][c]*inv_hw) instead of g ]
-__global__ void swish_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ sc,
-                                 const float* __restrict__ sh, int C, size_t hw, const float* __restrict__ se_s,
-                                 const float* __restrict__ gpool, float inv_hw, float* __restrict__ out, size_t n4) {
-  const size_t per_img = hw * (size_t)C / 4;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((i * 4) % (size_t)C);
-    f4 gv = *(const f4*)(g + i * 4);
-    if (se_s) {
-      const size_t n = i / per_img;
-      gv = gv * *(const f4*)(se_s + n * C + c) + *(const f4*)(gpool + n * C + c) * inv_hw;
-    }
-    const f4 z = *(const f4*)(y + i * 4) * *(const f4*)(sc + c) + *(const f4*)(sh + c);
-    *(f4*)(out + i * 4) = gv * dswish4(z);
-  }
-}
-hipError_t launch_swish_bwd(const float* g, const float* y, const float* sc, const float* sh, int C, int N, size_t hw,
-                            const float* se_s, const float* gpool, float* out, hipStream_t st) {
-  const size_t n4 = (size_t)N * hw * C / 4;
-  hipLaunchKernelGGL(swish_bwd_kernel, dim3(nb(n4, 256)), dim3(256), 0, st, g, y, sc, sh, C, hw, se_s, gpool,
-                     (float)(1.0 / (double)hw), out, n4);
-  return hipGetLastError();
-}
-
 // ---------------------------------------------------------------- depthwise convolution
 // x [N][H][W][C] plain NHWC; w [k*k][C] (tap-major: tap t of channel c at w[t*C + c], the parameter-arena layout of a
 // depthwise layer, so a thread's four channels of one tap are ONE 16-byte load); pb = zero pad at the begin of H and W
@@ -130,11 +105,10 @@ static hipError_t dw_fwd_launch(const float* x, const float* w, int flip, int pb
   hipLaunchKernelGGL((dw_fwd_kernel<K, S, TH, MINB>), g, dim3(256), 0, st, x, w, flip, pb, H, W, C, Ho, Wo, addend, y);
   return hipGetLastError();
 }
-static int dw_variant() { static int v = -1; if (v < 0) { const char* e = getenv("UWM_DW_VARIANT"); v = e ? atoi(e) : 0; } return v; }
+// bands of TH = 4 output rows (8 rows: 256 VGPRs / 1 wave per SIMD, slower; 2 rows: the halo is re-loaded too often)
 template <int K, int S>
 static hipError_t dw_any(const float* x, const float* w, int flip, int pb, int N, int H, int W, int C, int Ho, int Wo, const float* addend,
                          float* y, hipStream_t st) {
-  if (dw_variant() == 1) return dw_fwd_launch<K, S, 2, 1>(x, w, flip, pb, N, H, W, C, Ho, Wo, addend, y, st);
   return dw_fwd_launch<K, S, 4, 1>(x, w, flip, pb, N, H, W, C, Ho, Wo, addend, y, st);
 }
 hipError_t launch_dw_fwd(const float* x, const float* w, int k, int stride, int pb, int N, int H, int W, int C, int Ho, int Wo,
@@ -206,14 +180,9 @@ hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, i
     return hipErrorInvalidValue;
   }
   if (stride != 2 || (k != 3 && k != 5)) return hipErrorInvalidValue;
-  const int th = dw_variant() == 1 ? 4 : 8;
-  dim3 g; dw_grid(W * (C / 4), (H + th - 1) / th, N, &g);
-#define DW_S2(KK, PO, TT) hipLaunchKernelGGL((dw_dgrad_s2_kernel<KK, PO, TT>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx)
-  if (th == 8) {
-    if (k == 3 && !(pb & 1)) DW_S2(3, 0, 8); else if (k == 3) DW_S2(3, 1, 8); else if (!(pb & 1)) DW_S2(5, 0, 8); else DW_S2(5, 1, 8);
-  } else {
-    if (k == 3 && !(pb & 1)) DW_S2(3, 0, 4); else if (k == 3) DW_S2(3, 1, 4); else if (!(pb & 1)) DW_S2(5, 0, 4); else DW_S2(5, 1, 4);
-  }
+  dim3 g; dw_grid(W * (C / 4), (H + 7) / 8, N, &g);
+#define DW_S2(KK, PO) hipLaunchKernelGGL((dw_dgrad_s2_kernel<KK, PO, 8>), g, dim3(256), 0, st, dy, w, pb, H, W, C, Ho, Wo, addend, dx)
+  if (k == 3 && !(pb & 1)) DW_S2(3, 0); else if (k == 3) DW_S2(3, 1); else if (!(pb & 1)) DW_S2(5, 0); else DW_S2(5, 1);
 #undef DW_S2
   return hipGetLastError();
 }
@@ -671,15 +640,4 @@ hipError_t launch_rowscale(const float* g, const float* rowscale, int N, size_t 
   hipLaunchKernelGGL(rowscale_kernel, dim3(nb(n4, 256)), dim3(256), 0, st, g, rowscale, hw, C, out, n4);
   return hipGetLastError();
 }
-// acc += g
-__global__ void accum_kernel(const float* __restrict__ g, float* __restrict__ acc, size_t n4) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-    *(f4*)(acc + i * 4) = *(const f4*)(acc + i * 4) + *(const f4*)(g + i * 4);
-}
-hipError_t launch_accum(const float* g, float* acc, size_t n, hipStream_t st) {
-  const size_t n4 = n / 4;
-  hipLaunchKernelGGL(accum_kernel, dim3(nb(n4, 256)), dim3(256), 0, st, g, acc, n4);
-  return hipGetLastError();
-}
-
 }  // namespace uwm

@@ -154,9 +154,6 @@ hipError_t launch_preprocess_mask(const uint8_t* m, int N, int H, int W, int thr
 // EfficientNet MBConv pieces (mbconv.hip): swish, depthwise k x k conv (weights tap-major [k*k][C]) with static "same"
 // padding (pb = pad at the begin of H and W; the end pad is implied by Ho/Wo), squeeze-and-excitation, block output with drop-connect
 hipError_t launch_swish_fwd(const float* y, const float* sc, const float* sh, int C, float* out, size_t npix, hipStream_t st);
-// out = g' * swish'(y*sc+sh), g' = g (se_s == nullptr) or g*se_s[n][c] + gpool[n][c]/hw (SE backward folded in)
-hipError_t launch_swish_bwd(const float* g, const float* y, const float* sc, const float* sh, int C, int N, size_t hw,
-                            const float* se_s, const float* gpool, float* out, hipStream_t st);
 hipError_t launch_dw_fwd(const float* x, const float* w, int k, int stride, int pb, int N, int H, int W, int C,
                          int Ho, int Wo, float* y, hipStream_t st);
 hipError_t launch_dw_dgrad(const float* dy, const float* w, int k, int stride, int pb, int N, int H, int W, int C,
@@ -185,7 +182,6 @@ hipError_t launch_se_scale(const float* a, const float* s, int N, size_t hw, int
 hipError_t launch_mb_out(const float* y, const float* sc, const float* sh, const float* rowscale, const float* id, int N, size_t hw,
                          int C, float* out, hipStream_t st);
 hipError_t launch_rowscale(const float* g, const float* rowscale, int N, size_t hw, int C, float* out, hipStream_t st);
-hipError_t launch_accum(const float* g, float* acc, size_t n, hipStream_t st);
 
 // loss / metrics (loss.hip)
 hipError_t launch_loss(const float* logits, int ld, const void* target, int tdtype, size_t npix_total,

@@ -887,8 +887,6 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
   for (int k = (sb < 1 ? 1 : sb); effnet && k < se && k <= 4; ++k) {
     const int s = 4 - k;
     const int lo = s == 0 ? 0 : m->feat_blk[s - 1] + 1;
-    auto bn_ss = [&](int ci, const float** sc, const float** sh_) { const BNL& b = m->bns[m->convs[ci].bn]; *sc = c.F(b.f_off) + 2 * b.C; *sh_ = c.F(b.f_off) + 3 * b.C; };
-    const float *sc, *sf;
     for (int bi = m->feat_blk[s]; bi >= lo; --bi) {
       const MBL& b = m->mb[bi];
       const int ho = p.mh[bi], wo = p.mw[bi], hi = ho * b.stride, wi = wo * b.stride;
