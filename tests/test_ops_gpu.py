@@ -148,6 +148,32 @@ def test_conv1x1_shapes(cuda, shape):
     _conv_case(cuda, n, cin, cout, h, w, 1, 1, 0, lazy=True, seed=2)
 
 
+@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 1, 2, 32, 48), (16, 3, 1, 20, 36), (8, 1, 1, 9, 17), (32, 4, 2, 16, 16), (16, 2, 1, 64, 300)])
+def test_conv_head_streaming_kernel(cuda, cin, cout, n, h, w):
+    """conv_head.hip (3x3 segmentation head, <= 4 classes): forced (cfg 500) and auto-routed, plain and lazy sources, bias,
+    zero padding applied after the producer's activation, odd sizes (ragged 4-row bands)."""
+    L = lib()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    scale = torch.rand(cin, generator=g) + 0.5; scale[::3] *= -1
+    shift = torch.randn(cin, generator=g) * 0.3
+    wp, kpad = pack_w(wt)
+    bp = torch.zeros(4); bp[:cout] = bias
+    xd, wd, bd, scd, shd = nhwc(x).to(cuda), wp.to(cuda), bp.to(cuda), scale.to(cuda), shift.to(cuda)
+    for lazy in (False, True):
+        xin = torch.relu(x * scale[:, None, None] + shift[:, None, None]) if lazy else x
+        ref = F.conv2d(xin, wt, bias, 1, 1)
+        for cfg in (500, -1):
+            y = torch.full((n, h, w, 4), float("nan"), device=cuda)
+            s0 = src(xd, scd if lazy else None, shd if lazy else None, relu=1 if lazy else 0)
+            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wd), cout, kpad, 3, 3, 1, 1, n, 4, P(bd), P(y), None, cfg, stream()))
+            torch.cuda.synchronize()
+            assert (nchw(y.cpu(), cout) - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+            assert (y[..., cout:] == 0).all()
+
+
 def test_conv_lazy_bn_relu_prologue(cuda):
     # consumer-side BatchNorm-apply + ReLU (negative scales included) and zero padding AFTER it
     _conv_case(cuda, 2, 64, 64, 16, 16, 3, 1, 1, lazy=True)

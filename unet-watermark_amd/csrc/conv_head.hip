@@ -1,0 +1,112 @@
+// Segmentation head: 3x3 / stride 1 / pad 1 convolution from a few channels (8 | 16 | 32) to <= 4 classes at full
+// resolution, with bias — smp SegmentationHead(16 -> classes, k=3) (/root/reference/src/models/
+// unet_model.py:64-71 -> smp).  0.04 GMAC per image: pure HBM streaming (read C floats, write 4 per pixel), which the
+// MFMA implicit GEMM served badly (a 128x16 tile for 1 live output channel, nine separate tap gathers: 486 us for the
+// 16x16x512x512 layer against ~75 us of HBM time).  Here a thread owns an output column and walks the image in bands of
+// TH = 4 rows: per input row it loads its three columns' channel quads once (lanes run along W: contiguous memory, the
+// neighbours' columns hit in L1), applies the producer's lazy BatchNorm scale/shift + ReLU, and feeds up to three output
+// rows; the 9*C weights per class sit in LDS and are read as broadcasts.  One 16-byte store per pixel (classes padded to 4).
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int CQ, int NCO>
+__global__ __launch_bounds__(256) void conv_head_kernel(const ConvArgs a) {
+  constexpr int TH = 4, C = CQ * 4;
+  __shared__ f4 ws[NCO * 9 * CQ];
+  for (int i = threadIdx.x; i < NCO * 9 * CQ; i += 256) {
+    const int co = i / (9 * CQ), r = i - co * 9 * CQ;                // r = tap * CQ + cq
+    ws[i] = co < a.wrows ? *(const f4*)(a.w + (size_t)co * a.Kpad + r * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const int H = a.Ho, W = a.Wo;
+  const int nbands = (H + TH - 1) / TH;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nbands * W) return;
+  const int band = idx / W, wo = idx - band * W;
+  const int n = blockIdx.y, ho0 = band * TH;
+  const bool lazy = a.s0.scale != nullptr;
+  const int relu = a.s0.relu;
+  f4 sc[CQ], sh[CQ];
+#pragma unroll
+  for (int q = 0; q < CQ; ++q) {
+    sc[q] = lazy ? *(const f4*)(a.s0.scale + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+    sh[q] = lazy ? *(const f4*)(a.s0.shift + q * 4) : (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  float acc[TH][NCO];
+#pragma unroll
+  for (int j = 0; j < TH; ++j)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[j][co] = (a.bias && co < a.wrows) ? a.bias[co] : 0.f;
+  const float* xn = a.s0.ptr + (size_t)n * H * W * C;
+#pragma unroll
+  for (int rr = 0; rr < TH + 2; ++rr) {
+    const int hi = ho0 - 1 + rr;
+    if (hi < 0 || hi >= H) continue;
+    const float* row = xn + (size_t)hi * W * C;
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      const int wi = wo - 1 + s_;
+      if (wi < 0 || wi >= W) continue;                  // zero padding applies AFTER the producer's activation
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        f4 v = *(const f4*)(row + (size_t)wi * C + q * 4);
+        if (lazy) {
+          v = v * sc[q] + sh[q];
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+#pragma unroll
+        for (int j = 0; j < TH; ++j) {
+          const int r = rr - j;                         // compile-time after unrolling
+          if (r >= 0 && r < 3) {
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) {
+              const f4 wv = ws[(co * 9 + r * 3 + s_) * CQ + q];
+              acc[j][co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TH; ++j) {
+    const int ho = ho0 + j;
+    if (ho < H) {
+      f4 o = {0.f, 0.f, 0.f, 0.f};
+      o.x = acc[j][0];
+      if (NCO > 1) { o.y = acc[j][NCO > 1 ? 1 : 0]; o.z = acc[j][NCO > 2 ? 2 : 0]; o.w = acc[j][NCO > 3 ? 3 : 0]; }
+      *(f4*)(a.out + (((size_t)n * H + ho) * W + wo) * 4) = o;
+    }
+  }
+}
+
+bool conv_head_applicable(const ConvArgs& a) {
+  return a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && a.rmul == 1 && a.off == -1 && a.Cout == 4 && a.wrows >= 1 && a.wrows <= 4 &&
+         (a.Ctot == 8 || a.Ctot == 16 || a.Ctot == 32) && a.C0 == a.Ctot && a.s0.C == a.Ctot && a.s0.up == 0 && a.Ho == a.Hl && a.Wo == a.Wl &&
+         !a.ssum && !a.addend && !a.mask && !a.out_up;
+}
+
+template <int CQ>
+static hipError_t launch_head(const ConvArgs& a, hipStream_t st) {
+  const int nbands = (a.Ho + 3) / 4;
+  const dim3 g((unsigned)((nbands * a.Wo + 255) / 256), (unsigned)a.N);
+  if (prof_on()) prof_begin(30, a.flops, st);
+  if (a.wrows == 1) hipLaunchKernelGGL((conv_head_kernel<CQ, 1>), g, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_head_kernel<CQ, 4>), g, dim3(256), 0, st, a);
+  if (prof_on()) prof_end(st);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_head(const ConvArgs& a, hipStream_t st) {
+  if (!conv_head_applicable(a)) return hipErrorInvalidValue;
+  switch (a.Ctot) {
+    case 8: return launch_head<2>(a, st);
+    case 16: return launch_head<4>(a, st);
+    default: return launch_head<8>(a, st);
+  }
+}
+
+}  // namespace uwm

@@ -320,9 +320,12 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
     fprintf(stderr, "conv %s N=%d Ctot=%d(C0=%d up=%d) Cout=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d smul=%d sdiv=%d wino=%d gflop=%.2f\n",
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
             (int)(cfg < 0 && winograd_enabled() && conv_wino_applicable(a)), a.flops * 1e-9);
+  if (cfg == 500) return launch_conv_head(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
   if (a.out_up) return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;   // fused concat split: Winograd epilogue only
   if (cfg == 200) return launch_conv_patch16(a, st);
+  static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
+  if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);      // few channels -> <= 4 classes: HBM streaming kernel
   // 16-channel inputs at full resolution are HBM-bound: the one-barrier direct kernel beats the Winograd pipeline there
   if (cfg < 0 && winograd_enabled() && conv_wino_applicable(a) && !conv_patch16_applicable(a)) return launch_conv_wino(a, st);
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);

@@ -71,7 +71,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 30 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128
+enum { kProfClasses = 31 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_begin(int cls, double flops, hipStream_t st);
@@ -95,6 +95,9 @@ hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn);
 // Winograd F(2x2,3x3) (conv_wino.hip): needs a.wu = launch_wino_weights(a.w ...) output; force_cfg 300 (auto tile) / 300+BN
 bool conv_wino_applicable(const ConvArgs& a);
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn = 0);   // bn 8 = conv_wino8
+// segmentation head (3x3, 8|16|32 channels -> <= 4 classes, bias): HBM streaming kernel (conv_head.hip); force_cfg 500
+bool conv_head_applicable(const ConvArgs& a);
+hipError_t launch_conv_head(const ConvArgs& a, hipStream_t st);
 bool conv_wino8_applicable(const ConvArgs& a);              // 512-thread, 16x16-pixel, 64-channel variant (conv_wino8.hip)
 hipError_t launch_conv_wino8(const ConvArgs& a, hipStream_t st);
 size_t wino_weights_floats(int wrows, int Ctot);

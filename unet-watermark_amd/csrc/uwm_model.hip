@@ -1281,9 +1281,9 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
-  if ((cfg >= 300 || (cfg < 0 && winograd_enabled())) && op_wino_shape(a, kh, kw, stride, pad)) {
+  if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_enabled())) && op_wino_shape(a, kh, kw, stride, pad)) {
     if (op_wino_prepare(a, 0, (hipStream_t)stream)) return 1;
-  } else if (cfg >= 300) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
+  } else if (cfg >= 300 && cfg < 500) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
   LCHK(launch_conv(a, (hipStream_t)stream, cfg));
   return 0;
 }
