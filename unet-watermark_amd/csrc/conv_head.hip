@@ -83,6 +83,100 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const ConvArgs a) {
   }
 }
 
+// dgrad of the same layer: dx[h][w][c] = sum over (r, s, class) dy[h+1-r][w+1-s][class] * W[class][c][r][s], then the ReLU
+// mask of the tensor the head read.  dy has 4 (padded) channels, dx has C = 8 | 16 | 32: read 16 B, write C*4 B (+ mask
+// C*4 B) per pixel.  Same walk: a thread owns a column and bands of 4 rows, loads its three columns of dy once per row and
+// feeds up to three output rows; the repacked filter wd[c][tap*4 + class] sits in LDS as [tap][class][channel quad].
+template <int CQ, int NCO>
+__global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) {
+  constexpr int TH = 4, C = CQ * 4;
+  __shared__ f4 ws[9 * NCO * CQ];
+  for (int i = threadIdx.x; i < 9 * NCO * CQ; i += 256) {
+    const int q = i % CQ, tc = i / CQ, co = tc % NCO, tap = tc / NCO;
+    f4 v;
+    v.x = a.w[(size_t)(q * 4 + 0) * a.Kpad + tap * 4 + co]; v.y = a.w[(size_t)(q * 4 + 1) * a.Kpad + tap * 4 + co];
+    v.z = a.w[(size_t)(q * 4 + 2) * a.Kpad + tap * 4 + co]; v.w = a.w[(size_t)(q * 4 + 3) * a.Kpad + tap * 4 + co];
+    ws[i] = v;
+  }
+  __syncthreads();
+  const int H = a.Ho, W = a.Wo;
+  const int nbands = (H + TH - 1) / TH;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= nbands * W) return;
+  const int band = idx / W, wo = idx - band * W;
+  const int n = blockIdx.y, ho0 = band * TH;
+  f4 acc[TH][CQ];
+#pragma unroll
+  for (int j = 0; j < TH; ++j)
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) acc[j][q] = (f4){0.f, 0.f, 0.f, 0.f};
+  const float* gn = a.s0.ptr + (size_t)n * H * W * 4;
+#pragma unroll
+  for (int rr = 0; rr < TH + 2; ++rr) {
+    const int hh = ho0 - 1 + rr;
+    if (hh < 0 || hh >= H) continue;
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int ww = wo - 1 + s2;
+      if (ww < 0 || ww >= W) continue;
+      const f4 g = *(const f4*)(gn + ((size_t)hh * W + ww) * 4);
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int j = 0; j < TH; ++j) {
+        const int r = j + 2 - rr;                       // filter row that maps output row ho0+j to dy row hh (compile-time)
+        if (r >= 0 && r < 3) {
+          const int tap = r * 3 + (2 - s2);
+#pragma unroll
+          for (int co = 0; co < NCO; ++co)
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) acc[j][q] += ws[(tap * NCO + co) * CQ + q] * gv[co];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TH; ++j) {
+    const int ho = ho0 + j;
+    if (ho >= H) continue;
+    const size_t o = (((size_t)n * H + ho) * W + wo) * C;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+      f4 v = acc[j][q];
+      if (a.addend) v += *(const f4*)(a.addend + o + q * 4);
+      if (a.mask) {
+        f4 mk = *(const f4*)(a.mask + o + q * 4);
+        if (a.mscale) mk = mk * *(const f4*)(a.mscale + q * 4) + *(const f4*)(a.mshift + q * 4);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      *(f4*)(a.out + o + q * 4) = v;
+    }
+  }
+}
+
+bool conv_head_dgrad_applicable(const ConvArgs& a) {
+  return a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && a.rmul == -1 && a.off == 1 && a.Ctot == 4 && a.C0 == 4 && a.s0.C == 4 &&
+         (a.Cout == 8 || a.Cout == 16 || a.Cout == 32) && a.wrows == a.Cout && a.s0.up == 0 && !a.s0.scale && a.Ho == a.Hl && a.Wo == a.Wl &&
+         !a.ssum && !a.bias && !a.out_up;
+}
+template <int CQ>
+static hipError_t launch_head_dgrad(const ConvArgs& a, hipStream_t st) {
+  const int nbands = (a.Ho + 3) / 4;
+  const dim3 g((unsigned)((nbands * a.Wo + 255) / 256), (unsigned)a.N);
+  if (prof_on()) prof_begin(30, a.flops, st);
+  if (a.live_ch == 1) hipLaunchKernelGGL((conv_head_dgrad_kernel<CQ, 1>), g, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_head_dgrad_kernel<CQ, 4>), g, dim3(256), 0, st, a);
+  if (prof_on()) prof_end(st);
+  return hipGetLastError();
+}
+hipError_t launch_conv_head_dgrad(const ConvArgs& a, hipStream_t st) {
+  if (!conv_head_dgrad_applicable(a)) return hipErrorInvalidValue;
+  switch (a.Cout) {
+    case 8: return launch_head_dgrad<2>(a, st);
+    case 16: return launch_head_dgrad<4>(a, st);
+    default: return launch_head_dgrad<8>(a, st);
+  }
+}
+
 bool conv_head_applicable(const ConvArgs& a) {
   return a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && a.rmul == 1 && a.off == -1 && a.Cout == 4 && a.wrows >= 1 && a.wrows <= 4 &&
          (a.Ctot == 8 || a.Ctot == 16 || a.Ctot == 32) && a.C0 == a.Ctot && a.s0.C == a.Ctot && a.s0.up == 0 && a.Ho == a.Hl && a.Wo == a.Wl &&

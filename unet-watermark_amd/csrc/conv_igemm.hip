@@ -325,7 +325,8 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.out_up) return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;   // fused concat split: Winograd epilogue only
   if (cfg == 200) return launch_conv_patch16(a, st);
   static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
-  if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);      // few channels -> <= 4 classes: HBM streaming kernel
+  if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);
+  if (cfg < 0 && !no_head && conv_head_dgrad_applicable(a)) return launch_conv_head_dgrad(a, st);      // few channels -> <= 4 classes: HBM streaming kernel
   // 16-channel inputs at full resolution are HBM-bound: the one-barrier direct kernel beats the Winograd pipeline there
   if (cfg < 0 && winograd_enabled() && conv_wino_applicable(a) && !conv_patch16_applicable(a)) return launch_conv_wino(a, st);
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);

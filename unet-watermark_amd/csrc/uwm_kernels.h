@@ -51,6 +51,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   float* out_up; int up_c0; const float* up_mask; const float* up_mscale; const float* up_mshift;
   int up_accum;              // out_up += instead of = (a tensor with several consumers: UNet++)
   int pc_ntaps[4]; unsigned pc_taps[4];          // stride-2 dgrad parity classes (conv_igemm.hip; blockIdx.y = class), set by the launcher
+  int live_ch;               // dgrad: channels of dY that can be non-zero (0 = all; the head's classes inside its 4 padded channels)
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
 };
@@ -98,6 +99,8 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn = 0);   //
 // segmentation head (3x3, 8|16|32 channels -> <= 4 classes, bias): HBM streaming kernel (conv_head.hip); force_cfg 500
 bool conv_head_applicable(const ConvArgs& a);
 hipError_t launch_conv_head(const ConvArgs& a, hipStream_t st);
+bool conv_head_dgrad_applicable(const ConvArgs& a);          // its dgrad (4 padded classes -> 8|16|32 channels, ReLU mask)
+hipError_t launch_conv_head_dgrad(const ConvArgs& a, hipStream_t st);
 bool conv_wino8_applicable(const ConvArgs& a);              // 512-thread, 16x16-pixel, 64-channel variant (conv_wino8.hip)
 hipError_t launch_conv_wino8(const ConvArgs& a, hipStream_t st);
 size_t wino_weights_floats(int wrows, int Ctot);

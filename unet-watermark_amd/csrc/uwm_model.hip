@@ -496,7 +496,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.w = c.F(cv.wd_off); a.wrows = cv.CinP; a.Kpad = cv.KpadD; a.ntaps = cv.k * cv.k; a.kw = cv.k;
   a.N = c.N; a.Ho = Hin; a.Wo = Win; a.Cout = cv.CinP; a.M = c.N * Hin * Win;
   a.Hl = Ho; a.Wl = Wo; a.smul = 1; a.rmul = -1; a.off = cv.pad; a.sdiv = cv.stride;
-  a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
+  a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift; a.live_ch = cv.Cout;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
   if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
