@@ -2,16 +2,20 @@
 // resolution, with bias — smp SegmentationHead(16 -> classes, k=3) (/root/reference/src/models/
 // unet_model.py:64-71 -> smp).  0.04 GMAC per image: pure HBM streaming (read C floats, write 4 per pixel), which the
 // MFMA implicit GEMM served badly (a 128x16 tile for 1 live output channel, nine separate tap gathers: 486 us for the
-// 16x16x512x512 layer against ~75 us of HBM time).  Here a thread owns an output column and walks the image in bands of
-// TH = 4 rows: per input row it loads its three columns' channel quads once (lanes run along W: contiguous memory, the
-// neighbours' columns hit in L1), applies the producer's lazy BatchNorm scale/shift + ReLU, and feeds up to three output
-// rows; the 9*C weights per class sit in LDS and are read as broadcasts.  One 16-byte store per pixel (classes padded to 4).
+// 16x16x512x512 layer against ~75 us of HBM time).  Here a lane owns one channel quad of an output column and walks the
+// image in bands of TH = 4 rows: per input row it loads its three columns once (lanes run along (W, quad): contiguous
+// memory, the neighbours' columns hit in L1), applies the producer's lazy BatchNorm scale/shift + ReLU, and feeds up to
+// three output rows; the 9*C weights per class sit in LDS.  The quads' partial dot products are added across adjacent lanes;
+// one 16-byte store per pixel (classes padded to 4).
 #include "uwm_kernels.h"
 
 namespace uwm {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Lane mapping (both kernels): consecutive lanes = the CQ channel quads of one pixel, then the next pixel along W, so
+// every wave-level load / store covers contiguous memory (with one pixel per lane each instruction touched 64 B of every
+// other 128-byte line: 4x the line requests; 189 -> ~100 us forward).
 template <int CQ, int NCO>
 __global__ __launch_bounds__(256) void conv_head_kernel(const ConvArgs a) {
   constexpr int TH = 4, C = CQ * 4;
@@ -24,69 +28,76 @@ __global__ __launch_bounds__(256) void conv_head_kernel(const ConvArgs a) {
   const int H = a.Ho, W = a.Wo;
   const int nbands = (H + TH - 1) / TH;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= nbands * W) return;
-  const int band = idx / W, wo = idx - band * W;
+  const int pix = idx / CQ, q = idx - pix * CQ;          // CQ divides 256: the quads of a pixel sit in one wave
+  const bool live = pix < nbands * W;
+  const int band = live ? pix / W : 0, wo = live ? pix - band * W : 0;
   const int n = blockIdx.y, ho0 = band * TH;
   const bool lazy = a.s0.scale != nullptr;
   const int relu = a.s0.relu;
-  f4 sc[CQ], sh[CQ];
-#pragma unroll
-  for (int q = 0; q < CQ; ++q) {
-    sc[q] = lazy ? *(const f4*)(a.s0.scale + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
-    sh[q] = lazy ? *(const f4*)(a.s0.shift + q * 4) : (f4){0.f, 0.f, 0.f, 0.f};
-  }
+  const f4 sc = lazy ? *(const f4*)(a.s0.scale + q * 4) : (f4){1.f, 1.f, 1.f, 1.f};
+  const f4 sh = lazy ? *(const f4*)(a.s0.shift + q * 4) : (f4){0.f, 0.f, 0.f, 0.f};
   float acc[TH][NCO];
 #pragma unroll
   for (int j = 0; j < TH; ++j)
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) acc[j][co] = (a.bias && co < a.wrows) ? a.bias[co] : 0.f;
-  const float* xn = a.s0.ptr + (size_t)n * H * W * C;
+    for (int co = 0; co < NCO; ++co) acc[j][co] = 0.f;
+  const float* xn = a.s0.ptr + (size_t)n * H * W * C + q * 4;
 #pragma unroll
   for (int rr = 0; rr < TH + 2; ++rr) {
     const int hi = ho0 - 1 + rr;
-    if (hi < 0 || hi >= H) continue;
+    if (!live || hi < 0 || hi >= H) continue;
     const float* row = xn + (size_t)hi * W * C;
 #pragma unroll
     for (int s_ = 0; s_ < 3; ++s_) {
       const int wi = wo - 1 + s_;
       if (wi < 0 || wi >= W) continue;                  // zero padding applies AFTER the producer's activation
+      f4 v = *(const f4*)(row + (size_t)wi * C);
+      if (lazy) {
+        v = v * sc + sh;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
 #pragma unroll
-      for (int q = 0; q < CQ; ++q) {
-        f4 v = *(const f4*)(row + (size_t)wi * C + q * 4);
-        if (lazy) {
-          v = v * sc[q] + sh[q];
-          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        }
+      for (int j = 0; j < TH; ++j) {
+        const int r = rr - j;                           // compile-time after unrolling
+        if (r >= 0 && r < 3) {
 #pragma unroll
-        for (int j = 0; j < TH; ++j) {
-          const int r = rr - j;                         // compile-time after unrolling
-          if (r >= 0 && r < 3) {
-#pragma unroll
-            for (int co = 0; co < NCO; ++co) {
-              const f4 wv = ws[(co * 9 + r * 3 + s_) * CQ + q];
-              acc[j][co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
-            }
+          for (int co = 0; co < NCO; ++co) {
+            const f4 wv = ws[(co * 9 + r * 3 + s_) * CQ + q];
+            acc[j][co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
           }
         }
       }
     }
   }
+  // add the CQ channel-quad partials of each pixel (adjacent lanes), lane q == 0 stores
 #pragma unroll
-  for (int j = 0; j < TH; ++j) {
-    const int ho = ho0 + j;
-    if (ho < H) {
-      f4 o = {0.f, 0.f, 0.f, 0.f};
-      o.x = acc[j][0];
-      if (NCO > 1) { o.y = acc[j][NCO > 1 ? 1 : 0]; o.z = acc[j][NCO > 2 ? 2 : 0]; o.w = acc[j][NCO > 3 ? 3 : 0]; }
-      *(f4*)(a.out + (((size_t)n * H + ho) * W + wo) * 4) = o;
+  for (int j = 0; j < TH; ++j)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      float v = acc[j][co];
+#pragma unroll
+      for (int d = 1; d < CQ; d <<= 1) v += __shfl_xor(v, d);
+      acc[j][co] = v;
+    }
+  if (live && q == 0) {
+#pragma unroll
+    for (int j = 0; j < TH; ++j) {
+      const int ho = ho0 + j;
+      if (ho < H) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) o[co] = acc[j][co] + ((a.bias && co < a.wrows) ? a.bias[co] : 0.f);
+        *(f4*)(a.out + (((size_t)n * H + ho) * W + wo) * 4) = (f4){o[0], o[1], o[2], o[3]};
+      }
     }
   }
 }
 
 // dgrad of the same layer: dx[h][w][c] = sum over (r, s, class) dy[h+1-r][w+1-s][class] * W[class][c][r][s], then the ReLU
 // mask of the tensor the head read.  dy has 4 (padded) channels, dx has C = 8 | 16 | 32: read 16 B, write C*4 B (+ mask
-// C*4 B) per pixel.  Same walk: a thread owns a column and bands of 4 rows, loads its three columns of dy once per row and
-// feeds up to three output rows; the repacked filter wd[c][tap*4 + class] sits in LDS as [tap][class][channel quad].
+// C*4 B) per pixel.  Same walk and lane mapping: a lane owns one channel quad of a pixel column and bands of 4 rows, loads
+// its three columns of dy once per row (the quad's lanes share the address) and feeds up to three output rows; the
+// repacked filter wd[c][tap*4 + class] sits in LDS as [tap][class][channel quad].
 template <int CQ, int NCO>
 __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) {
   constexpr int TH = 4, C = CQ * 4;
@@ -102,14 +113,13 @@ __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) 
   const int H = a.Ho, W = a.Wo;
   const int nbands = (H + TH - 1) / TH;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= nbands * W) return;
-  const int band = idx / W, wo = idx - band * W;
+  const int pix = idx / CQ, q = idx - pix * CQ;
+  if (pix >= nbands * W) return;
+  const int band = pix / W, wo = pix - band * W;
   const int n = blockIdx.y, ho0 = band * TH;
-  f4 acc[TH][CQ];
+  f4 acc[TH];
 #pragma unroll
-  for (int j = 0; j < TH; ++j)
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) acc[j][q] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < TH; ++j) acc[j] = (f4){0.f, 0.f, 0.f, 0.f};
   const float* gn = a.s0.ptr + (size_t)n * H * W * 4;
 #pragma unroll
   for (int rr = 0; rr < TH + 2; ++rr) {
@@ -127,9 +137,7 @@ __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) 
         if (r >= 0 && r < 3) {
           const int tap = r * 3 + (2 - s2);
 #pragma unroll
-          for (int co = 0; co < NCO; ++co)
-#pragma unroll
-            for (int q = 0; q < CQ; ++q) acc[j][q] += ws[(tap * NCO + co) * CQ + q] * gv[co];
+          for (int co = 0; co < NCO; ++co) acc[j] += ws[(tap * NCO + co) * CQ + q] * gv[co];
         }
       }
     }
@@ -138,18 +146,15 @@ __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) 
   for (int j = 0; j < TH; ++j) {
     const int ho = ho0 + j;
     if (ho >= H) continue;
-    const size_t o = (((size_t)n * H + ho) * W + wo) * C;
-#pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-      f4 v = acc[j][q];
-      if (a.addend) v += *(const f4*)(a.addend + o + q * 4);
-      if (a.mask) {
-        f4 mk = *(const f4*)(a.mask + o + q * 4);
-        if (a.mscale) mk = mk * *(const f4*)(a.mscale + q * 4) + *(const f4*)(a.mshift + q * 4);
-        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-      }
-      *(f4*)(a.out + o + q * 4) = v;
+    const size_t o = (((size_t)n * H + ho) * W + wo) * C + q * 4;
+    f4 v = acc[j];
+    if (a.addend) v += *(const f4*)(a.addend + o);
+    if (a.mask) {
+      f4 mk = *(const f4*)(a.mask + o);
+      if (a.mscale) mk = mk * *(const f4*)(a.mscale + q * 4) + *(const f4*)(a.mshift + q * 4);
+      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
     }
+    *(f4*)(a.out + o) = v;
   }
 }
 
@@ -161,7 +166,7 @@ bool conv_head_dgrad_applicable(const ConvArgs& a) {
 template <int CQ>
 static hipError_t launch_head_dgrad(const ConvArgs& a, hipStream_t st) {
   const int nbands = (a.Ho + 3) / 4;
-  const dim3 g((unsigned)((nbands * a.Wo + 255) / 256), (unsigned)a.N);
+  const dim3 g((unsigned)(((size_t)nbands * a.Wo * CQ + 255) / 256), (unsigned)a.N);
   if (prof_on()) prof_begin(30, a.flops, st);
   if (a.live_ch == 1) hipLaunchKernelGGL((conv_head_dgrad_kernel<CQ, 1>), g, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_head_dgrad_kernel<CQ, 4>), g, dim3(256), 0, st, a);
@@ -186,7 +191,7 @@ bool conv_head_applicable(const ConvArgs& a) {
 template <int CQ>
 static hipError_t launch_head(const ConvArgs& a, hipStream_t st) {
   const int nbands = (a.Ho + 3) / 4;
-  const dim3 g((unsigned)((nbands * a.Wo + 255) / 256), (unsigned)a.N);
+  const dim3 g((unsigned)(((size_t)nbands * a.Wo * CQ + 255) / 256), (unsigned)a.N);
   if (prof_on()) prof_begin(30, a.flops, st);
   if (a.wrows == 1) hipLaunchKernelGGL((conv_head_kernel<CQ, 1>), g, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_head_kernel<CQ, 4>), g, dim3(256), 0, st, a);
