@@ -186,7 +186,9 @@ typedef struct {
   int C, H, W, up, relu;
 } uwm_src;
 /* y[N][Ho][Wo][Cout] = conv(cat(s0,s1), w) ; w [Cout][Kpad] packed (k = tap*Ctot + c).
- * stats (2*Cout doubles: sum, sumsq; pre-zeroed) may be NULL. */
+ * stats (2*Cout doubles: sum, sumsq; pre-zeroed) may be NULL.
+ * cfg: -1 = the library's routing; 0..5 implicit-GEMM tile configs; 100+BN direct patch kernel; 200 16-channel patch
+ * kernel; 300 (+BN, 308 = 8-wave) Winograd F(2x2,3x3); 500 segmentation-head streaming kernel (tests / timing). */
 int  uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
                  int pad, int N, int Cout, const float* bias, float* y, double* stats, int cfg, uwm_stream stream);
 /* dx[N][H][W][Cin] = conv_transpose(dy[N][Ho][Wo][Cout], wd) (+addend, *relu-mask) ; wd [Cin][KpadD] */
