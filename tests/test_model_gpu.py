@@ -532,6 +532,27 @@ def test_in_channels_1_and_custom_decoder(cuda):
     _grad_check(m, ref, l2_rel=6e-2, cos_min=0.998)
 
 
+def test_efficientnet_b4_in_channels_classes_and_custom_decoder(cuda):
+    """EfficientNet-b4 with a 1-channel input, 3 classes and a narrow decoder (decoder_channels[-1] = 8: the head runs
+    the 8-channel streaming kernel with NCO = 4)."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    kw = dict(in_channels=1, classes=3, decoder_channels=(128, 64, 32, 16, 8))
+    m, ref = _pair("efficientnet-b4", dev=cuda, seed=9, **kw)
+    m.drop_connect = False
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 1, 96, 128, generator=g)
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert (m(x.to(cuda)).cpu() - ref(x)).abs().max() < LOGIT_TOL
+    m.train(); ref.train()
+    out_ref = ref(x); (out_ref ** 2).mean().backward()
+    out = m(x.to(cuda)); (out ** 2).mean().backward()
+    assert out.shape == (3, 3, 96, 128)
+    assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
+    _effb4_grad_check(m, ref, l2_rel=1e-1, cos_min=0.995)
+
+
 def test_resize_threshold_matches_bilinear_reference(cuda):
     """predict.py:620-625: resize raw logits to the original image size (bilinear) then threshold."""
     import unet_watermark_amd as U
