@@ -73,7 +73,9 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   std::vector<size_t> a0, a1, a2, se;   // EfficientNet per block: swish(bn0(expand)), swish(bn1(dw)), SE-scaled, {pool[N][mid], s[N][mid], hpre[N][nsqP]}
   std::vector<int> mh, mw;          // EfficientNet per block: output height / width
   size_t dw_part = 0;               // EfficientNet: partial sums of the two-stage depthwise weight gradient (largest layer)
-  size_t se_g = 0, se_gn = 0, se_gq = 0;   // EfficientNet: SE backward scratch {gs [N][mid] + acc1 [N][nsq] (contiguous, within se_gn + se_gq floats), gpool [se_gn]}
+  size_t se_g = 0;                  // EfficientNet: SE backward gpool scratch [N][max mid]
+  std::vector<size_t> se_pool, se_gs;   // per block: pooled mean [N][mid] (forward) / {gs [N][mid], acc1 [N][nsq]} (backward), each set contiguous:
+  size_t se_pool_all = 0, se_pool_floats = 0, se_gs_all = 0, se_gs_floats = 0;   // ONE memset per forward / backward instead of one per block
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
@@ -360,6 +362,10 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
     p.stem_a = alloc((size_t)N * h * w * stemC);
     const size_t nb = m->mb.size();
     p.a0.assign(nb, 0); p.a1.assign(nb, 0); p.a2.assign(nb, 0); p.se.assign(nb, 0); p.mh.assign(nb, 0); p.mw.assign(nb, 0);
+    p.se_pool.assign(nb, 0); p.se_gs.assign(nb, 0);
+    for (size_t i = 0; i < nb; ++i) { p.se_pool[i] = p.se_pool_floats; p.se_pool_floats += (size_t)rup((long long)N * m->mb[i].mid, 64); }
+    p.se_pool_all = alloc(p.se_pool_floats);
+    for (size_t i = 0; i < nb; ++i) p.se_pool[i] += p.se_pool_all;
     for (; bi < nb; ++bi) {
       const MBL& b = m->mb[bi];
       const int hi = h, wi = w;
@@ -367,7 +373,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       if (b.ce >= 0) { place(b.ce, hi, wi); p.a0[bi] = alloc((size_t)N * hi * wi * b.mid); }
       place(b.cdw, h, w);
       p.a1[bi] = alloc((size_t)N * h * w * b.mid); p.a2[bi] = alloc((size_t)N * h * w * b.mid);
-      p.se[bi] = alloc((size_t)N * (2 * b.mid + 2 * (size_t)rup(b.nsq, 4)));
+      p.se[bi] = alloc((size_t)N * (b.mid + 2 * (size_t)rup(b.nsq, 4)));        // {s [N][mid], hpre [N][nsq], hid [N][nsq]}
       place(b.cp, h, w);
       p.oh[b.cr] = p.ow[b.cr] = p.oh[b.cx] = p.ow[b.cx] = 1;
       p.xn[bi] = alloc((size_t)N * h * w * b.Cout);
@@ -419,7 +425,10 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
       size_t max_part = 0;
       for (size_t i = 0; i < m->mb.size(); ++i) max_part = std::max(max_part, dw_wgrad_scratch_floats(m->mb[i].k, N, m->mb[i].mid, p.mh[i], p.mw[i]));
       p.dw_part = alloc(max_part);
-      p.se_g = alloc(2 * (size_t)N * (max_mid + max_nsq)); p.se_gn = (size_t)N * max_mid; p.se_gq = (size_t)N * max_nsq;
+      p.se_g = alloc((size_t)N * max_mid);
+      for (size_t i = 0; i < m->mb.size(); ++i) { p.se_gs[i] = p.se_gs_floats; p.se_gs_floats += (size_t)rup((long long)N * (m->mb[i].mid + m->mb[i].nsq), 64); }
+      p.se_gs_all = alloc(p.se_gs_floats);
+      for (size_t i = 0; i < m->mb.size(); ++i) p.se_gs[i] += p.se_gs_all;
     }
     h = H / 32; w = W / 32;                       // deepest feature: the decoder loop below doubles from here
     p.dcat.assign(m->dec.size(), 0); p.gskip.assign(m->dec.size(), 0);
@@ -659,6 +668,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     LCHK(launch_swish_fwd(c.F(p.y[m->stem]), sc, sf, m->f1C, c.F(p.stem_a), (size_t)N * h * w, st));
     f1 = mk_src(c.F(p.stem_a), m->f1C, h, w);
     m->keep_fwd = training ? m->keep : nullptr;
+    HIPCHK(hipMemsetAsync(c.F(p.se_pool_all), 0, p.se_pool_floats * sizeof(float), st));
     Src cur = f1;
     for (size_t bi = 0; bi < m->mb.size(); ++bi) {
       const MBL& b = m->mb[bi];
@@ -680,8 +690,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
         LCHK(run_bn_finalize(c, dw.bn, npo, 1));
       }
       bn_ss(b.cdw, &sc, &sf);
-      float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
-      HIPCHK(hipMemsetAsync(pool, 0, (size_t)N * b.mid * sizeof(float), st));
+      float* pool = c.F(p.se_pool[bi]); float* sv = c.F(p.se[bi]); float* hpre = sv + (size_t)N * b.mid;      // (pools zeroed by one memset above)
       LCHK(launch_swish_pool(c.F(p.y[b.cdw]), sc, sf, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, pool, st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_fwd(pool, m->params + cr.w_off, m->params + cr.bias_off, cr.Kpad, m->params + cx.w_off,
@@ -772,6 +781,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
     HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
+    if (p.se_gs_floats) HIPCHK(hipMemsetAsync(c.F(p.se_gs_all), 0, p.se_gs_floats * sizeof(float), st));
     if (m->packed_in_fwd && m->pack_mode == winograd_mode()) {      // (a mode switch between forward and backward: redo them)
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
     } else {
@@ -901,9 +911,8 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       LCHK(run_wgrad(c, b.cp, a2, nullptr, gO, ho, wo));
       LCHK(run_dgrad(c, b.cp, gO, ho, wo, ho, wo, gM, nullptr, nullptr, nullptr, nullptr));
       // squeeze-and-excitation: gs = sum_hw g*a1 ; FC backward ; g_a1 = g*s + gpool/hw, then through swish(bn1(.))
-      float* pool = c.F(p.se[bi]); float* sv = pool + (size_t)N * b.mid; float* hpre = sv + (size_t)N * b.mid;
-      float* gs = c.F(p.se_g); float* acc1 = gs + (size_t)N * b.mid; float* gpool = gs + p.se_gn + p.se_gq;
-      HIPCHK(hipMemsetAsync(gs, 0, (size_t)N * (b.mid + b.nsq) * sizeof(float), st));
+      float* pool = c.F(p.se_pool[bi]); float* sv = c.F(p.se[bi]); float* hpre = sv + (size_t)N * b.mid;
+      float* gs = c.F(p.se_gs[bi]); float* acc1 = gs + (size_t)N * b.mid; float* gpool = c.F(p.se_g);      // gs / acc1 zeroed at the start of the backward
       LCHK(launch_se_reduce_hw(gM, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, 1.f, gs, st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_bwd(gs, sv, hpre, pool, m->params + cr.w_off, cr.Kpad, m->params + cx.w_off, cx.Kpad, N, b.mid, b.nsq,
