@@ -211,7 +211,8 @@ def test_conv_upsample_concat(cuda):
     (2, 64, 128, 32, 32, 1, 2, 0),
     (1, 16, 1, 32, 32, 3, 1, 1),      # head dgrad: dy has 1 -> 4 padded channels (conv_head_dgrad streaming kernel)
     (2, 32, 3, 18, 20, 3, 1, 1),      # head dgrad, 3 classes -> 32 channels, ragged bands
-    (1, 8, 4, 9, 33, 3, 1, 1),        # head dgrad, 4 classes -> 8 channels
+    (1, 8, 4, 9, 33, 3, 1, 1),        # head dgrad, 4 classes -> 8 channels 
+    (3, 16, 1, 64, 70, 3, 1, 1),      # head layer over several images / bands / column blocks
     (1, 96, 32, 16, 16, 3, 1, 1),     # concat input (Ctot=96): dgrad output is the full dcat
     (2, 32, 16, 24, 40, 3, 1, 1),     # wgrad_patch<16>, partial 8x16 tiles
     (1, 64, 128, 16, 16, 3, 1, 1),    # wgrad_patch<64> with two output-channel tiles
