@@ -5,12 +5,14 @@ one process per GPU (torch.distributed over RCCL), synthetic data resident in HB
 A "step" = zero_grad + forward + Dice loss + backward + (bucketed gradient all-reduce) + Adam — the
 hot lines of /root/reference/src/train.py:86-105 — on configs[1] of BASELINE.json.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                       (= --gpus 1 --steps 100 --warmup 20)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded around every
-conv / wgrad launch on the compute stream during the timed region (uwm_prof_*); `cpu_baseline` times
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP event pairs attached to every conv / wgrad
+dispatch (hipExtLaunchKernelGGL, on the stream the kernel is launched on) during the timed region (uwm_prof_*);
+`roofline.frac` is EXECUTED MFMA FLOP/s over the fp32-MFMA peak (the Winograd kernels' algorithmic rate is a separate
+field); `cpu_baseline` times
 the CPU oracle (the reference's CPU path restated in plain torch) on this host's cores on a bounded
 sample of the same workload.
 """
@@ -95,11 +97,43 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
     return out
 
 
+def source_sha256() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/uwm.h, sorted): ties a committed PMC traffic file to the
+    code that produced it (the GPU box has no .git, so a commit SHA cannot be recomputed there)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "unet-watermark_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "unet-watermark_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "uwm.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def collect_prof(L, steps):
+    """-> ({kernel: entry}, ncls) from uwm_prof_collect ({launches, ms, algorithmic FLOPs, algorithmic bytes} per class)."""
+    prof = (C.c_double * (64 * 4))()
+    ncls = L.lib().uwm_prof_collect(prof, 64)
+    ents = {}
+    for c in range(ncls):
+        cnt, ms, fl, by = prof[c * 4], prof[c * 4 + 1], prof[c * 4 + 2], prof[c * 4 + 3]
+        if cnt > 0 and ms > 0:
+            name = L.lib().uwm_prof_class_name(c).decode()
+            wino = "wino" in name       # Winograd F(2x2,3x3): the MFMA pipe executes 16 multiplies per 36 direct ones
+            ents[name] = {"kernel": name, "launches_per_step": cnt / max(1, steps), "avg_us": round(1e3 * ms / cnt, 2),
+                          "ms_per_step": round(ms / max(1, steps), 3),
+                          "mfma_tflops": round(fl / ms / 1e9 / (WINO_RATIO if wino else 1.0), 2),
+                          "algorithmic_tflops": round(fl / ms / 1e9, 2),
+                          "algorithmic_bytes_per_launch": int(by / cnt), "algorithmic_GBps": round(by / ms / 1e6, 1),
+                          "_ms": ms, "_fl": fl, "_exec": fl / (WINO_RATIO if wino else 1.0)}
+    return ents
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (SURVEY 8d protocol: 20 warm-up + 100 timed)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--encoder", default="resnet34")
@@ -107,10 +141,10 @@ def main():
                     help="Unet = BASELINE.json's configs (headline); UnetPlusPlus = the reference's default MODEL.NAME (SURVEY 8 f3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
-    ap.add_argument("--prof-steps", type=int, default=3, help="timed steps (the last ones) that carry per-launch HIP events")
+    ap.add_argument("--prof-steps", type=int, default=5, help="timed steps (the last ones) whose conv launches carry HIP event pairs")
     ap.add_argument("--serial-steps", type=int, default=3,
                     help="extra UNTIMED steps after the timed region with the wgrad side stream off, to report the "
-                         "dominant kernel's un-overlapped launch time next to the overlapped one (0 = skip)")
+                         "dominant kernel alone next to its in-step (co-resident) figure (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -160,8 +194,8 @@ def main():
     for _ in range(args.warmup):
         loss = trainer.step(x, t)
     barrier()
-    # per-launch HIP events (uwm_prof_*) cost ~0.7 ms per step (two timestamped barrier packets per conv launch), so
-    # they are recorded for the LAST `prof_steps` steps of the timed region only; `kernels` / `roofline` come from those
+    # profiled launches go through hipExtLaunchKernelGGL with an event pair each (a little host work per launch), so only
+    # the LAST `prof_steps` steps of the timed region carry them; `kernels` / `roofline` come from those
     prof_steps = min(args.prof_steps, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -171,11 +205,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.lib().uwm_prof_enable(0)
-    prof = (C.c_double * (64 * 3))()
-    ncls = L.lib().uwm_prof_collect(prof, 64)
+    ents = collect_prof(L, prof_steps)
     loss_val = float(loss[0].item())
-    # un-overlapped kernel times (NOT part of `value`): same step with the wgrad side stream switched off
-    prof_s = None
+    # the dominant kernel ALONE (not part of `value`): the same step with the wgrad side stream switched off
+    ents_s = None
     if args.serial_steps > 0 and rank == 0 and world == 1:
         L.lib().uwm_set_side_stream(model._h, 0)
         trainer.step(x, t); torch.cuda.synchronize(dev)
@@ -184,8 +217,7 @@ def main():
             trainer.step(x, t)
         torch.cuda.synchronize(dev)
         L.lib().uwm_prof_enable(0)
-        prof_s = (C.c_double * (64 * 3))()
-        L.lib().uwm_prof_collect(prof_s, 64)
+        ents_s = collect_prof(L, args.serial_steps)
         L.lib().uwm_set_side_stream(model._h, 1)
 
     if world > 1:
@@ -194,31 +226,18 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        from oracle.unet_oracle import conv_flops
-        fwd, fwdbwd = conv_flops(args.encoder, s, s, arch=args.arch)
-        kernels = []
-        tot_ms = tot_fl = 0.0
-        for c in range(ncls):
-            cnt, ms, fl = prof[c * 3], prof[c * 3 + 1], prof[c * 3 + 2]
-            if cnt > 0:
-                name = L.lib().uwm_prof_class_name(c).decode()
-                ent = {"kernel": name, "launches_per_step": cnt / max(1, prof_steps),
-                       "avg_us": round(1e3 * ms / cnt, 2), "ms_per_step": round(ms / max(1, prof_steps), 3),
-                       "tflops": round(fl / ms / 1e9, 2)}
-                if "wino" in name:      # Winograd F(2x2,3x3): 16 MFMA multiplies per 36 direct ones
-                    ent["mfma_executed_tflops"] = round(fl / ms / 1e9 / WINO_RATIO, 2)
-                kernels.append(ent)
-                tot_ms += ms; tot_fl += fl
-        kernels.sort(key=lambda k: -k["ms_per_step"])
+        fwd, fwdbwd = model.conv_flops(s, s)
+        kernels = sorted(ents.values(), key=lambda k: -k["ms_per_step"])
+        tot_ms = sum(k["_ms"] for k in kernels); tot_fl = sum(k["_fl"] for k in kernels); tot_ex = sum(k["_exec"] for k in kernels)
         dom = kernels[0] if kernels else None
         ms_step = 1e3 * dt / args.steps
+        headline = args.arch == "Unet" and args.encoder == "resnet34" and s == 512 and n == 16
         out = {
             "metric": "train_images_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.arch}-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
-                                   + (f"(BASELINE.json configs[{1 if world == 1 else 2}])"
-                                      if (args.arch == "Unet" and args.encoder == "resnet34" and s == 512 and n == 16) else
+                                   + (f"(BASELINE.json configs[{1 if world == 1 else 2}])" if headline else
                                       "(the per-GPU workload of BASELINE.json configs[3]: SURVEY 8 a18)"
                                       if (args.arch == "Unet" and args.encoder == "efficientnet-b4" and s == 1024 and n == 4) else
                                       "(not a BASELINE config: SURVEY 8 f3 / a18 widening)"),
@@ -226,45 +245,57 @@ def main():
                        "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if (world > 1 or force_ddp) else "none")},
             "loss": round(loss_val, 6),
             "model_tflops": round(world * n * fwdbwd * args.steps / dt / 1e12, 2),
-            "roofline": None, "kernels": kernels,
+            "roofline": None,
         }
         if dom:
-            serial = None
-            if prof_s is not None:
-                for c in range(ncls):
-                    if L.lib().uwm_prof_class_name(c).decode() == dom["kernel"] and prof_s[c * 3] > 0:
-                        cnt, ms, fl = prof_s[c * 3], prof_s[c * 3 + 1], prof_s[c * 3 + 2]
-                        serial = {"avg_launch_us": round(1e3 * ms / cnt, 2), "achieved": round(fl / ms / 1e9, 2),
-                                  "frac": round(fl / ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
-                                  "mfma_executed_frac": (round(fl / ms / 1e9 / WINO_RATIO / F32_MATRIX_PEAK_TFLOPS, 4)
-                                                         if "wino" in dom["kernel"] else None),
-                                  "note": f"{args.serial_steps} extra untimed steps with the wgrad side stream off"}
+            P = F32_MATRIX_PEAK_TFLOPS
+            alone = None
+            if ents_s is not None and dom["kernel"] in ents_s:
+                a_ = ents_s[dom["kernel"]]
+                alone = {"avg_launch_us": a_["avg_us"], "achieved": a_["mfma_tflops"], "frac": round(a_["mfma_tflops"] / P, 4),
+                         "algorithmic_tflops": a_["algorithmic_tflops"],
+                         "note": f"{args.serial_steps} extra untimed steps with the wgrad side stream off (nothing co-resident)"}
             traffic = None
-            try:   # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-                   # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction); regenerated by scripts/pmc_summary.py
+            try:   # HBM bytes per launch from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                   # (FETCH_SIZE doubled: MI355X_MICROARCH.md's gfx950 correction), digested by scripts/pmc_summary.py.
+                   # Only a file made from THESE kernel sources is quoted.
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                ent = pm["kernels"].get(dom["kernel"])
-                if ent:
-                    traffic = {"hbm_bytes_per_launch": ent["hbm_bytes_per_launch"], "source": pm["source"]}
-            except Exception:
-                traffic = None
-            wino = "wino" in dom["kernel"]
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
-                               "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "avg_launch_us": dom["avg_us"],
-                               "algorithm": ("Winograd F(2x2,3x3), fp32: `achieved` counts the ALGORITHMIC (direct-convolution) "
-                                             "FLOPs of SURVEY.md 8(d); the kernel executes 1/2.25 of them on the MFMA pipe "
-                                             "(`mfma_executed`), so `frac` may exceed the direct-form ceiling") if wino else "direct",
-                               "mfma_executed": ({"tflops": round(dom["tflops"] / WINO_RATIO, 2),
-                                                  "frac": round(dom["tflops"] / WINO_RATIO / F32_MATRIX_PEAK_TFLOPS, 4)} if wino else None),
-                               "note": "launch durations in the timed region include co-residency with kernels of the "
-                                       "other stream (wgrad side stream); `unoverlapped` is the same kernel alone",
-                               "unoverlapped": serial,
-                               "all_conv_kernels": {"tflops": round(tot_fl / tot_ms / 1e9, 2),
-                                                    "frac": round(tot_fl / tot_ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 4),
-                                                    "share_of_step": round(tot_ms / max(1, prof_steps) / ms_step, 4)},
-                               "profiled_steps": f"last {prof_steps} of the {args.steps} timed steps"}
+                sha = source_sha256()
+                if pm.get("source_sha256") != sha:
+                    traffic = {"hbm_bytes_per_launch": None,
+                               "note": f"profiles/pmc_traffic.json was measured on kernel sources {pm.get('source_sha256')} "
+                                       f"(git {pm.get('git_sha')}), this run is {sha}: not quoted"}
+                else:
+                    e_ = pm["kernels"].get(dom["kernel"])
+                    if e_:
+                        hb = e_["hbm_bytes_per_launch"]
+                        traffic = {"hbm_bytes_per_launch": hb, "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                                   "ratio": round(hb / max(1, dom["algorithmic_bytes_per_launch"]), 3),
+                                   "fetch_bytes_per_launch": e_.get("fetch_bytes_per_launch"), "write_bytes_per_launch": e_.get("write_bytes_per_launch"),
+                                   "source_sha256": sha, "git_sha": pm.get("git_sha"), "source": pm["source"]}
+            except Exception as e:
+                traffic = {"hbm_bytes_per_launch": None, "note": f"no PMC traffic file: {type(e).__name__}"}
+            out["roofline"] = {
+                "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["mfma_tflops"], "peak": P, "unit": "TFLOP/s",
+                "frac": round(dom["mfma_tflops"] / P, 4),
+                "definition": "achieved = FLOPs the MFMA pipe EXECUTED per launch / average launch duration of the kernel with the "
+                              "largest share of kernel time, over the profiled steps of the timed region (dispatch-attached HIP "
+                              "events on the launch stream; co-resident with the other stream's kernels); peak = fp32 MFMA "
+                              "(v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md); frac = achieved / peak (never > 1)",
+                "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
+                "algorithmic": {"tflops": dom["algorithmic_tflops"],
+                                "note": "direct-convolution FLOPs of SURVEY.md 8(d) / the same duration; Winograd F(2x2,3x3) kernels "
+                                        "execute 1/2.25 of them, so this figure is NOT a utilisation"},
+                "alone": alone,
+                "step": {"mfma_tflops": round(tot_ex * 1e-9 / prof_steps / ms_step, 2),
+                         "frac": round(tot_ex * 1e-9 / prof_steps / ms_step / P, 4),
+                         "algorithmic_tflops": round(tot_fl * 1e-9 / prof_steps / ms_step, 2),
+                         "conv_kernel_ms_per_step": round(tot_ms / prof_steps, 3),
+                         "note": "all conv / wgrad launches of a step: executed MFMA FLOPs / WALL step time (two streams overlap, so "
+                                 "kernel ms per step may exceed the step)"},
+                "traffic": traffic,
+                "profiled_steps": f"last {prof_steps} of the {args.steps} timed steps"}
+            out["kernels"] = [{k: v for k, v in e.items() if not k.startswith("_")} for e in kernels]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch)
         print(json.dumps(out), flush=True)

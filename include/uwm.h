@@ -1,13 +1,15 @@
 /* libuwm — C ABI of the MI355X-native U-Net watermark-segmentation hot path.
  *
  * This is the drop-in boundary for ONE path of Dave-he/unet-watermark: the forward / backward of
- * smp.Unet(resnet18|resnet34) and its Dice + BCE loss, which the reference reaches through
- *   model = smp.Unet(**kwargs)                /root/reference/src/models/unet_model.py:64-71,93-120
+ * smp.Unet | smp.UnetPlusPlus (encoders resnet18 | resnet34 | resnet50 | efficientnet-b4; UnetPlusPlus is the
+ * reference's default MODEL.NAME, src/configs/config.py:15) and its Dice + BCE loss, which the reference reaches through
+ *   model = smp.Unet(**kwargs)                /root/reference/src/models/unet_model.py:17-27,64-71,93-120
  *   outputs = model(images)                    /root/reference/src/train.py:91,100,142 ; src/predict.py:339,611
  *   loss = criterion(outputs, masks)           /root/reference/src/train.py:94,103 ; src/utils/losses.py:11-52
  *   loss.backward(); optimizer.step()          /root/reference/src/train.py:96-98,104-105
  *   metrics(sigmoid(outputs), masks)           /root/reference/src/train.py:110-117 ; src/utils/metrics.py:11-37
  *   (mask > THRESHOLD) * 255                   /root/reference/src/predict.py:614-625
+ * plus the data-parallel gradient exchange the reference lacks: uwm_allreduce_grads over RCCL.
  * The reference is pure Python and has no FFI of its own; INTEGRATION.md shows the ctypes stub a
  * maintainer adds (unet-watermark_amd/_lib.py is that stub).
  *
@@ -16,7 +18,10 @@
  *     data_ptr()); the library never allocates or frees device memory, never synchronises the
  *     host and enqueues all work on the caller's stream (a hipStream_t passed as void*).
  *   - every function returns 0 on success, non-zero on failure; uwm_last_error() then returns a
- *     thread-local message.  A handle is bound to one device and is not re-entrant.
+ *     thread-local message.  A handle is bound to one device — the device its arenas live on (uwm_bind reads it from
+ *     the parameter pointer); uwm_forward / uwm_backward / uwm_allreduce_grads make that device current for the
+ *     duration of the call, so the caller's current device need not match.  The free functions (uwm_loss, uwm_adam,
+ *     uwm_stats ...) launch on the caller's stream and expect that stream's device to be current.  Not re-entrant.
  *   - activations are NHWC fp32 with channels padded to a multiple of 4; logits are returned as
  *     [N][H][W][CP], CP = uwm_logits_channels() (class k at channel k).
  *   - parameters live in ONE flat fp32 arena (caller-owned) whose layout the library defines:
@@ -80,7 +85,8 @@ int  uwm_tensor_info_get(uwm_handle h, int index, uwm_tensor_info* out);
 int  uwm_logits_channels(uwm_handle h);
 
 /* number of backward stages (gradient buckets) and the arena range [begin,end) each one
- * completes; stage 0 = head+decoder, then encoder layer4, layer3, layer2, layer1+stem. */
+ * completes; stage 0 = head+decoder, then the encoder from its deepest group to the stem (ResNet: layer4, layer3,
+ * layer2, layer1+stem; EfficientNet-b4: blocks 22-31, 10-21, 6-9, 0-5+stem). */
 int  uwm_num_stages(uwm_handle h);
 int  uwm_stage_range(uwm_handle h, int stage, long long* begin, long long* end);
 
@@ -88,6 +94,9 @@ int  uwm_stage_range(uwm_handle h, int stage, long long* begin, long long* end);
 int  uwm_bind(uwm_handle h, float* params, float* grads, float* buffers);
 
 size_t uwm_workspace_bytes(uwm_handle h, int N, int H, int W, int training);
+/* algorithmic (direct-convolution) FLOPs per image at H x W: forward, and forward + backward (= 3x forward minus the
+ * stem's dgrad) — SURVEY.md 8(d)'s roofline numerator (62.512 / 186.303 GFLOP for Unet-resnet34 at 512x512) */
+int  uwm_conv_flops(uwm_handle h, int H, int W, double* fwd, double* fwd_bwd);
 
 /* logits[N][H][W][CP] = Unet(x[N][Cin][H][W]).  training!=0: BatchNorm uses batch statistics,
  * updates running stats, and the workspace keeps what uwm_backward needs.  H, W % 32 == 0. */
@@ -122,6 +131,11 @@ int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float l
 int  uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, long long step, float grad_scale, float max_norm, void* scratch,
                    uwm_stream stream);
+/* torch.optim.SGD(lr, momentum, weight_decay) (coupled L2, dampening 0; the reference's OPTIMIZER.NAME == "SGD" branch,
+ * /root/reference/src/train.py:272-278) over a flat range: buf = step == 1 ? g' : momentum*buf + g', p -= lr*buf with
+ * g' = grad_scale*g + weight_decay*p; max_norm > 0 adds global-norm clipping as uwm_adam_clip (scratch >= 8 bytes). */
+int  uwm_sgd(float* p, const float* g, float* buf, long long n, float lr, float momentum, float weight_decay,
+             long long step, float grad_scale, float max_norm, void* scratch, uwm_stream stream);
 int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
 /* Staged backward under data parallelism: uwm_backward runs its weight-gradient kernels on an internal side stream and,
  * by default, makes the caller's stream wait for them before it returns.  With a join stream set (the stream the
@@ -129,6 +143,14 @@ int  uwm_scale(float* p, long long n, float s, uwm_stream stream);
  * stream continues into the next stage while the side stream drains; the last stage joins both.  NULL restores the
  * default. */
 int  uwm_set_join_stream(uwm_handle h, uwm_stream stream);
+/* The data-parallel exchange itself (nothing comparable exists in the reference, which has no DDP):
+ * SUM all-reduce, in place, of the gradient-arena ranges of backward stages [stage_begin, stage_end) over the RCCL
+ * communicator `nccl_comm` (an ncclComm_t), one ncclAllReduce per stage, enqueued on `stream` (the communication
+ * stream — order it behind uwm_backward of those stages with an event, or hand it to uwm_set_join_stream).  Averaging
+ * is the optimizer's grad_scale = 1/world.  RCCL is not linked: ncclAllReduce is looked up in the host process (the
+ * library that created the communicator), else librccl.so.1 is opened. */
+int  uwm_allreduce_grads(uwm_handle h, void* nccl_comm, int stage_begin, int stage_end, uwm_stream stream);
+float* uwm_grad_arena(uwm_handle h);     /* the bound gradient arena (NULL before uwm_bind) */
 /* Input pipeline on the device (src/utils/dataset.py:298-395 get_*_transform tails): uint8 HWC images [N][H][W][C] ->
  * Normalize(mean, std) of x/255 as NCHW fp32 (what uwm_forward takes); uint8 masks [N][H][W] -> (m > threshold) as
  * uint8 {0,1} (what uwm_loss takes).  flags (device int[N] or NULL): bit0 HorizontalFlip, bit1 VerticalFlip, bits 2-3
@@ -138,11 +160,15 @@ int  uwm_preprocess_u8(const uint8_t* images, int N, int H, int W, int C, const 
                        const int* flags, float* out_nchw, uwm_stream stream);
 int  uwm_preprocess_mask_u8(const uint8_t* masks, int N, int H, int W, int threshold, const int* flags, uint8_t* out,
                             uwm_stream stream);
-/* 3x3/stride-1 convolutions (forward and dgrad) run as Winograd F(2x2,3x3) on the fp32 MFMA path by default
- * (2.25x fewer multiplies, results within a few fp32 ulps of the direct form); 0 selects the direct kernels
- * everywhere; 2 (tests) prefers the 512-thread Winograd variant wherever its shape rules allow, whatever the
- * launch size.  Process-wide; also UWM_WINOGRAD=0 in the environment. */
+/* 3x3/stride-1 convolutions (forward, dgrad and weight gradient) run as Winograd F(2x2,3x3) on the fp32 MFMA path by
+ * default (2.25x fewer multiplies, results within a few fp32 ulps of the direct form); mode 0 selects the direct
+ * kernels everywhere; 2 (tests) prefers the 512-thread Winograd variant wherever its shape rules allow, whatever the
+ * launch size.  uwm_set_winograd_mode is PER HANDLE.  uwm_set_winograd sets the process default, which the
+ * single-operator entry points (uwm_op_*) use and which a handle takes at uwm_create (also UWM_WINOGRAD=0 in the
+ * environment); it does not change existing handles. */
 int  uwm_set_winograd(int on);
+int  uwm_set_winograd_mode(uwm_handle h, int mode);
+int  uwm_get_winograd_mode(uwm_handle h);
 /* EfficientNet encoders only: stochastic depth ("drop connect") of the MBConv blocks in training mode.  `rowscale` is a
  * device array [uwm_num_mbconv_blocks][N] holding, per block and sample, keep/(1 - p_block) with keep in {0,1}; the host
  * draws it each step (uwm_mbconv_drop_rate gives p_block; blocks without identity skip ignore their row).  NULL (the
@@ -167,9 +193,11 @@ int  uwm_resize_threshold(const float* logits, int ld, int N, int h, int w, int 
  * per backward stage) so they overlap the dgrad chain; this switches that off/on at run time (default on). */
 int  uwm_set_side_stream(uwm_handle h, int on);
 
-/* Optional HIP-event profiler: while enabled every conv / wgrad launch is bracketed by a hipEvent pair
- * recorded on its launch stream.  uwm_prof_collect waits for the events and returns, per kernel class,
- * {launches, total ms, total algorithmic FLOPs} in out[class*3 + 0..2]; returns the number of classes. */
+/* Optional HIP-event profiler: while enabled every conv / wgrad launch carries a hipEvent pair attached to the kernel
+ * dispatch itself (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, the clock rocprofv3's kernel trace
+ * reads).  uwm_prof_collect waits for the events and returns, per kernel class, {launches, total ms, total algorithmic
+ * FLOPs, total algorithmic HBM bytes} in out[class*4 + 0..3] (out: >= 4*max_classes doubles); returns the number of
+ * classes. */
 int  uwm_prof_enable(int on);
 int  uwm_prof_collect(double* out, int max_classes);
 const char* uwm_prof_class_name(int cls);

@@ -20,10 +20,9 @@ for mode in ("eval", "train"):      # eval first: the train-mode forwards update
     with torch.no_grad():
         o32 = ref(x); o64 = ref64(x.double())
     for wino in (1, 0):
-        L.lib().uwm_set_winograd(wino)
+        L.check(L.lib().uwm_set_winograd_mode(m._h, wino))
         with torch.no_grad():
             o = m(x.to(dev)).cpu()
         print(f"{enc} {n}x{h}x{w} {mode:5s} winograd={wino}: |hip-oracle32| {float((o - o32).abs().max()):.2e}  "
               f"|hip-oracle64| {float((o.double() - o64).abs().max()):.2e}  |oracle32-oracle64| {float((o32.double() - o64).abs().max()):.2e}  "
               f"logit range {float(o32.abs().max()):.2f}")
-L.lib().uwm_set_winograd(1)

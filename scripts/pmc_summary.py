@@ -1,7 +1,10 @@
 """Digest rocprofv3 --pmc passes of `bench.py` (FETCH_SIZE, WRITE_SIZE, MFMA-busy) into profiles/:
    usage: scripts/pmc_summary.py <fetch_dir> <write_dir> <mfma_dir> <tag>
-   writes profiles/<tag>_pmc_summary.json and profiles/pmc_traffic.json (read by bench.py for roofline.traffic)."""
-import collections, csv, glob, json, re, sys
+   writes profiles/<tag>_pmc_summary.json and profiles/pmc_traffic.json (read by bench.py for roofline.traffic; carries the
+   sha256 of the kernel sources it was measured on, and GIT_SHA from the environment)."""
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_sha256
 fd, wd, md, tag = sys.argv[1:5]
 def norm(k):
     k = k.split("(")[0].replace("void uwm::", "").replace("uwm::", "")
@@ -29,8 +32,10 @@ for k in sorted(dur, key=lambda k: -dur[k])[:16]:
     rows.append(dict(kernel=k, launches=cnt[k], avg_us=round(dur[k] / cnt[k], 1), fetch_bytes_raw=int(fe), fetch_bytes_x2=int(2 * fe),
                      write_bytes=int(wr), mfma_busy_frac=round(busy / (gui / 8 * 1024), 3) if gui else None,
                      clock_GHz=round(gui / 8 / (dur[k] * 1e3), 2) if dur[k] else None))
-    traffic[alias.get(k, k)] = {"hbm_bytes_per_launch": int(2 * fe + wr)}
+    traffic[alias.get(k, k)] = {"hbm_bytes_per_launch": int(2 * fe + wr), "fetch_bytes_per_launch": int(2 * fe), "write_bytes_per_launch": int(wr)}
 json.dump(rows, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 json.dump({"source": f"profiles/{tag}_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; FETCH_SIZE x2 (gfx950), per launch",
+           "source_sha256": source_sha256(),          # the kernel sources these counters were measured on (bench.py refuses another)
+           "git_sha": os.environ.get("GIT_SHA"),      # commit of that tree (handed in by the caller: the GPU box has no .git)
            "kernels": traffic}, open("profiles/pmc_traffic.json", "w"), indent=1)
 for r in rows[:8]: print(r)

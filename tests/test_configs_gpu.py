@@ -1,0 +1,159 @@
+"""BASELINE.json's configurations at FULL size under `-m gpu` (round 1 only ran them at toy sizes under pytest):
+config 2 (Unet-resnet34 512x512: the oracle check bench.py prints, as a test), config 4 (Unet-efficientnet-b4
+1024x1024 bs4: the per-GPU workload) and config 5 (bs64 x 512x512 hipGraph-captured inference).  Oracle comparisons
+use the largest batch the CPU oracle finishes in seconds; the rest are size-independent properties at the full batch
+(finite, staged == whole backward, loss falls, batch independence bit for bit, graph replay == eager)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3        # BASELINE.json north_star: mask outputs within 1e-3 max-abs of the fp32 CPU reference
+
+
+def _grad_cos_l2(model, ref):
+    gref = dict(ref.named_parameters())
+    worst_cos, worst_l2 = 1.0, 0.0
+    for n, p in model.named_parameters():
+        g, r = p.grad.detach().cpu().double().flatten(), gref[n].grad.double().flatten()
+        if float(r.norm()) == 0:
+            continue
+        worst_cos = min(worst_cos, float(g @ r / (g.norm() * r.norm())))
+        worst_l2 = max(worst_l2, float((g - r).norm() / r.norm()))
+    return worst_cos, worst_l2
+
+
+def test_config2_resnet34_512_bs2_vs_oracle(cuda):
+    """The check bench.py's cpu_baseline leg prints next to every perf number (SURVEY 8d "parity checks reported with every
+    perf number"), as a test: Unet-resnet34 at the bench resolution, train-mode BatchNorm, identical weights — logits
+    <= 1e-3, Dice loss 1e-5, mask IoU, gradient cosine."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    ref = O.build("resnet34", seed=42)
+    m = U.Unet("resnet34").to(cuda)
+    m.load_state_dict(ref.state_dict())
+    m.train(); ref.train()
+    x, t = O.synthetic_batch(2, 512, 512, seed=42)
+    o_ref = ref(x); l_ref = O.DiceLoss(smooth=1e-5)(o_ref, t.unsqueeze(1)); l_ref.backward()
+    o = m(x.to(cuda)); l = U.DiceLoss(mode="binary", smooth=1e-5)(o, t.unsqueeze(1).to(cuda)); l.backward()
+    lg, lr = o.detach().cpu(), o_ref.detach()
+    assert float((lg - lr).abs().max()) < LOGIT_TOL
+    assert abs(float(l.detach()) - float(l_ref.detach())) < 1e-5
+    a, b = lg > 0, lr > 0
+    assert float((a & b).sum()) / max(1.0, float((a | b).sum())) > 0.9995          # mask IoU vs CPU ref (BASELINE metric)
+    cos, l2 = _grad_cos_l2(m, ref)
+    assert cos > 0.9995 and l2 < 3e-2, (cos, l2)
+
+
+def test_config4_full_size_effb4_1024_bs4(cuda):
+    """BASELINE config 4's per-GPU workload, Unet(efficientnet-b4) at 4x3x1024x1024 — the size at which 32-bit patch
+    offsets, the static 'same'-pad chain and the workspace plan matter: (a) oracle parity of a 1x3x1024x1024 train-mode
+    forward (logits <= 1e-3, Dice 1e-5); (b) full batch: finite, staged == whole backward, loss falls over 3 Trainer
+    steps; (c) eval-mode batch independence bit for bit."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    from unet_watermark_amd.train import Trainer
+    ref = O.build("efficientnet-b4", seed=7)
+    m = U.Unet("efficientnet-b4").to(cuda)
+    m.load_state_dict(ref.state_dict())
+    m.drop_connect = False
+    # (a) oracle parity at the full resolution (batch 1: what the CPU oracle finishes in seconds)
+    x1, t1 = O.synthetic_batch(1, 1024, 1024, seed=11)
+    m.train(); ref.train()
+    with torch.no_grad():
+        o_ref = ref(x1)                    # the oracle drops blocks only when handed keep masks: none here
+        o = m(x1.to(cuda))
+    assert o.shape == (1, 1, 1024, 1024)
+    err = float((o.cpu() - o_ref).abs().max())
+    assert err < LOGIT_TOL, err
+    l_ref = float(O.DiceLoss(smooth=1e-5)(o_ref, t1.unsqueeze(1)))
+    l = float(U.DiceLoss(mode="binary", smooth=1e-5)(o, t1.unsqueeze(1).to(cuda)))
+    assert abs(l - l_ref) < 1e-5
+    del ref
+    # (b) the full batch
+    x, t = O.synthetic_batch(4, 1024, 1024, seed=12)
+    x, t = x.to(cuda), t.to(cuda)
+
+    def run(staged):
+        logits = m._forward_raw(x, training=True)
+        dl = torch.zeros_like(logits)
+        dl[..., 0] = torch.randn(logits.shape[:-1], device=cuda, generator=torch.Generator(device="cuda").manual_seed(1)) * 1e-4
+        if staged:
+            for k in range(len(m.stages)):
+                m._backward_raw(dl, k, k + 1)
+        else:
+            m._backward_raw(dl)
+        torch.cuda.synchronize()
+        return logits, m.flat_grads().clone()
+
+    (lg, a), (_, b), (_, c) = run(False), run(False), run(True)
+    assert torch.isfinite(lg).all() and torch.isfinite(a).all() and float(a.abs().max()) > 0
+    checked = 0
+    for name, kind, arena, off, shp, strd in m._infos:
+        if arena != 0 or (name.endswith("_bn2.bias") and "_blocks" in name):
+            continue
+        va, vb, vc = (g.as_strided(shp, strd, off).double() for g in (a, b, c))
+        if float(va.norm()) == 0:
+            continue
+        noise = float((va - vb).norm() / va.norm()); diff = float((vc - va).norm() / va.norm())
+        assert diff <= max(1e-5, 10 * noise), f"{name}: staged vs whole {diff:.2e}, run-to-run {noise:.2e}"
+        checked += 1
+    assert checked > 50
+    tr = Trainer(m, w_dice=0.5, w_bce=0.5, lr=1e-3)
+    l0 = float(tr.step(x, t)[0])
+    for _ in range(3):
+        l1 = float(tr.step(x, t)[0])
+    assert l1 == l1 and l1 < l0, (l0, l1)
+    # (c) eval: every image of the batch equals its own batch-1 forward, bit for bit
+    m.eval()
+    with torch.no_grad():
+        full = m(x).clone()
+        for i in (0, 3):
+            assert torch.equal(m(x[i:i + 1])[0], full[i])
+    assert torch.isfinite(full).all()
+
+
+def test_config5_bs64_512_hipgraph(cuda):
+    """BASELINE config 5 at its real size: Unet-resnet34, 64x3x512x512, eval-mode forward captured in a hipGraph and
+    replayed (/root/reference/src/predict.py:339-357,610-625 runs batch 1 per image): replay == eager == the batch-1 path
+    bit for bit; two images against the oracle's eval forward <= 1e-3; masks by the reference's raw-logit threshold equal
+    the oracle's except where the oracle's own logit sits within 1e-3 of the threshold."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    from unet_watermark_amd.predict import WatermarkPredictor
+    from unet_watermark_amd.config import get_cfg_defaults
+    ref = O.build("resnet34", seed=42)
+    m = U.Unet("resnet34").to(cuda)
+    m.load_state_dict(ref.state_dict())
+    # representative running statistics (a fresh net's 0/1 statistics do not normalise: logits of +-70): a few train-mode
+    # forwards on the HIP model, then BOTH models carry those buffers
+    xs, _ = O.synthetic_batch(8, 512, 512, seed=5)
+    m.train()
+    with torch.no_grad():
+        for k in range(3):
+            m(xs.to(cuda) * (1.0 + 0.1 * k))
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    cfg = get_cfg_defaults(); cfg.MODEL.NAME = "Unet"
+    pred = WatermarkPredictor(model=m, config=cfg, device=cuda)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(64, 3, 512, 512, generator=g).to(cuda)
+    eager = pred.logits(x, use_graph=False).clone()
+    rep = pred.logits(x, use_graph=True).clone()
+    assert torch.equal(eager, rep)
+    x2 = torch.roll(x, 1, 0)
+    rep2 = pred.logits(x2, use_graph=True).clone()                 # second replay of the same graph, new input
+    assert torch.equal(rep2, torch.roll(eager, 1, 0))
+    for i in (0, 31, 63):
+        assert torch.equal(pred.logits(x[i:i + 1], use_graph=False)[0], eager[i])
+    ref.eval()
+    with torch.no_grad():
+        o_ref = ref(x[:2].cpu())
+    err = float((eager[:2].cpu() - o_ref).abs().max())
+    assert err < LOGIT_TOL, err
+    thr = pred.threshold
+    mask = pred.predict_mask(x, use_graph=True)[:2].cpu()
+    assert mask.dtype == torch.uint8 and set(mask.unique().tolist()) <= {0, 255}
+    ref_mask = ((o_ref[:, 0] > thr).to(torch.uint8) * 255)
+    differ = mask != ref_mask
+    assert not bool((differ & ((o_ref[:, 0] - thr).abs() > LOGIT_TOL)).any())
+    assert float(differ.float().mean()) < 1e-4

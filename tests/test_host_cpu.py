@@ -199,3 +199,98 @@ def test_workspace_plan_sizes(U):
     lib.uwm_destroy(h)
     assert 6.5 < gib[("Unet", "resnet34")] < 8.5, gib           # BASELINE config 2: ~7.5 GB of the 288 GB
     assert gib[("UnetPlusPlus", "resnet34")] < 16 and gib[("UnetPlusPlus", "resnet50")] < 30, gib
+
+
+def test_conv_flops_match_survey_and_oracle(U):
+    """uwm_conv_flops (the roofline numerator bench.py uses, so the bench needs nothing from oracle/) = SURVEY 8(d)'s
+    figures and the oracle's independent count, for every encoder / decoder the build serves."""
+    from oracle import unet_oracle as O
+    f, fb = U.Unet("resnet34").conv_flops(512, 512)
+    assert round(f / 1e9, 3) == 62.512 and round(fb / 1e9, 3) == 186.303
+    for enc, arch, hw in [("resnet18", "Unet", 256), ("resnet50", "Unet", 512), ("efficientnet-b4", "Unet", 1024),
+                          ("resnet34", "UnetPlusPlus", 512)]:
+        got = getattr(U, arch)(enc).conv_flops(hw, hw)
+        ref = O.conv_flops(enc, hw, hw, arch=arch)
+        assert all(abs(a - b) <= 1e-9 * b for a, b in zip(got, ref)), (enc, arch, got, ref)
+
+
+def test_fused_optimizer_state_interchanges_with_torch_optim(U):
+    """The fused optimizers save / load torch.optim's own state layout per parameter in logical (OIHW) shape
+    (/root/reference/src/train.py:323-326,441-458 resumes `optimizer_state_dict` of optim.Adam): a torch Adam state loads
+    into FusedAdam and back; an unknown layout is skipped with a warning instead of raising."""
+    import warnings
+    from unet_watermark_amd.train import FusedAdam, FusedSGD
+    torch.manual_seed(3)
+    m = U.Unet("resnet18")
+    params = list(m.parameters())
+    ref = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-4)
+    for p in params:
+        p.grad = torch.randn_like(p) * 1e-2
+    ref.step(); ref.step()
+    sd = ref.state_dict()
+    opt = FusedAdam(m, lr=5e-4)
+    opt.load_state_dict(sd)
+    assert opt._step == 2 and opt.param_groups[0]["lr"] == 1e-3 and opt.param_groups[0]["weight_decay"] == 1e-4
+    views_m, views_v = opt._views(opt._bufs[0]), opt._views(opt._bufs[1])
+    for i, p in enumerate(params):
+        assert torch.equal(views_m[i], sd["state"][i]["exp_avg"]) and torch.equal(views_v[i], sd["state"][i]["exp_avg_sq"])
+    # arena padding (rows padded to 32 floats) stays zero: the moments cover exactly the logical elements
+    assert float(opt._bufs[0].abs().sum()) == pytest.approx(float(sum(s["exp_avg"].abs().sum() for s in sd["state"].values())), rel=1e-5)
+    out = opt.state_dict()
+    assert set(out) == {"state", "param_groups"} and len(out["state"]) == len(params)
+    assert out["param_groups"][0]["params"] == list(range(len(params)))
+    assert all(tuple(out["state"][i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(params))
+    ref2 = torch.optim.Adam(params, lr=1.0)
+    ref2.load_state_dict(out)                                   # torch accepts what we write
+    assert torch.equal(ref2.state[params[5]]["exp_avg"], sd["state"][5]["exp_avg"])
+    assert float(ref2.state[params[5]]["step"]) == 2.0
+    # round-1 flat layout still loads; a foreign layout warns and leaves the state untouched
+    opt2 = FusedAdam(m)
+    opt2.load_state_dict({"step": 7, "exp_avg": opt._bufs[0].clone(), "exp_avg_sq": opt._bufs[1].clone(), "param_groups": [{"lr": 0.25}]})
+    assert opt2._step == 7 and torch.equal(opt2._bufs[0], opt._bufs[0]) and opt2.param_groups[0]["lr"] == 0.25
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        opt2.load_state_dict({"foo": 1})
+        FusedSGD(m).load_state_dict(sd)                         # Adam slots offered to SGD
+    assert len(w) == 2 and opt2._step == 7
+    sgd = torch.optim.SGD(params, lr=1e-2, momentum=0.9)
+    sgd.step()
+    fs = FusedSGD(m)
+    fs.load_state_dict(sgd.state_dict())
+    assert torch.equal(fs._views(fs._bufs[0])[3], sgd.state[params[3]]["momentum_buffer"])
+    # frozen parameters are refused, not silently trained
+    params[0].requires_grad_(False)
+    with pytest.raises(NotImplementedError):
+        opt._check_frozen()
+
+
+def test_soft_dice_iou_and_early_stopping(U):
+    """dice_coef / iou_score (/root/reference/src/utils/metrics.py:39-54) and the EarlyStopping rule
+    (/root/reference/src/train.py:37-66) the CLI applies identically on every rank."""
+    p = torch.tensor([[0.9, 0.1], [0.8, 0.0]]); t = torch.tensor([[1, 0], [1, 0]])
+    i, sp, st = 1.7, 1.8, 2.0
+    assert U.dice_coef(p, t) == pytest.approx((2 * i + 1e-5) / (sp + st + 1e-5), rel=1e-6)
+    assert U.iou_score(p, t) == pytest.approx((i + 1e-5) / (sp + st - i + 1e-5), rel=1e-6)
+    assert U.dice_coef(torch.zeros(4), torch.zeros(4)) == pytest.approx(1.0)
+    from unet_watermark_amd.cli import EarlyStopping, _make_scheduler
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.w = torch.nn.Parameter(torch.zeros(1))
+    mm = M(); es = EarlyStopping(patience=2)
+    seq = [1.0, 0.9, 0.95, 0.91]
+    res = []
+    for k, v in enumerate(seq):
+        with torch.no_grad():
+            mm.w.fill_(float(k))
+        res.append(es(v, mm))
+    assert res == [False, False, False, True] and float(mm.w) == 1.0      # stops after 2 bad epochs, restores the best weights
+    from unet_watermark_amd.config import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    assert cfg.MODEL.NAME == "UnetPlusPlus"                                # the reference's default (src/configs/config.py:15)
+    o = torch.optim.SGD(mm.parameters(), lr=0.1)
+    assert isinstance(_make_scheduler(cfg, o), torch.optim.lr_scheduler.ReduceLROnPlateau)
+    cfg.OPTIMIZER.LR_SCHEDULER = "CosineAnnealingLR"; cfg.TRAIN.EPOCHS = 7
+    sc = _make_scheduler(cfg, o)
+    assert isinstance(sc, torch.optim.lr_scheduler.CosineAnnealingLR) and sc.T_max == 7
+    cfg.OPTIMIZER.LR_SCHEDULER = "none"
+    assert _make_scheduler(cfg, o) is None

@@ -139,9 +139,10 @@ def test_resnet50_bottleneck_encoder_parity(cuda, arch, n, h, w):
 
 @pytest.mark.parametrize("fwd_mode,bwd_mode", [(0, 0), (1, 0), (0, 1)])
 def test_direct_kernels_and_winograd_switch_between_forward_and_backward(cuda, fwd_mode, bwd_mode):
-    """uwm_set_winograd(0) = the direct kernels everywhere (dcat + upsplit decoder backward, packed dgrad banks for every
-    layer); switching the mode BETWEEN a forward and its backward must re-derive the dgrad filter banks instead of
-    using the ones the forward prepared for the other mode."""
+    """Winograd mode 0 (per handle: uwm_set_winograd_mode) = the direct kernels everywhere (dcat + upsplit decoder
+    backward, packed dgrad banks for every layer); switching the mode BETWEEN a forward and its backward must re-derive
+    the dgrad filter banks instead of using the ones the forward prepared for the other mode.  A second handle in the
+    same process keeps its own mode."""
     import unet_watermark_amd as U
     from unet_watermark_amd import _lib as L
     from oracle import unet_oracle as O
@@ -150,14 +151,15 @@ def test_direct_kernels_and_winograd_switch_between_forward_and_backward(cuda, f
     m.train(); ref.train()
     crit_ref = O.DiceLoss(smooth=1e-5); crit = U.DiceLoss(mode="binary", smooth=1e-5)
     out_ref = ref(x); crit_ref(out_ref, t.unsqueeze(1)).backward()
-    try:
-        L.lib().uwm_set_winograd(fwd_mode)
-        out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda))
-        L.lib().uwm_set_winograd(bwd_mode)
-        loss.backward()
-        torch.cuda.synchronize()
-    finally:
-        L.lib().uwm_set_winograd(1)
+    other = U.Unet("resnet18").to(cuda)
+    assert L.lib().uwm_get_winograd_mode(m._h) == 1 and L.lib().uwm_get_winograd_mode(other._h) == 1
+    L.check(L.lib().uwm_set_winograd_mode(m._h, fwd_mode))
+    out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda))
+    L.check(L.lib().uwm_set_winograd_mode(m._h, bwd_mode))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert L.lib().uwm_get_winograd_mode(other._h) == 1          # per handle, not process-wide
+    assert L.lib().uwm_set_winograd_mode(m._h, 7) != 0           # rejected
     assert (out.detach().cpu() - out_ref.detach()).abs().max() < LOGIT_TOL
     _grad_check(m, ref)
 
@@ -582,6 +584,45 @@ def test_adam_with_global_norm_clipping(cuda):
                                   C.c_void_p(scr.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert abs(float(scr[0]) ** 0.5 - float(gr.norm())) < 1e-3 * float(gr.norm())
     assert (p.cpu() - pr.detach()).abs().max() < 2e-6
+
+
+def test_sgd_kernel_and_trainer_optimizer_choice(cuda):
+    """uwm_sgd == torch.optim.SGD(momentum=0.9, weight_decay) — the reference's OPTIMIZER.NAME == "SGD" branch
+    (/root/reference/src/train.py:272-278) — 3 steps, with and without global-norm clipping; Trainer(optimizer="SGD")."""
+    import ctypes as C
+    import unet_watermark_amd as U
+    from unet_watermark_amd import _lib as L
+    from unet_watermark_amd.train import Trainer, FusedSGD
+    g = torch.Generator().manual_seed(2)
+    n = 70001
+    for max_norm in (0.0, 0.5):
+        p0 = torch.randn(n, generator=g)
+        pr = p0.clone().requires_grad_()
+        opt = torch.optim.SGD([pr], lr=1e-2, momentum=0.9, weight_decay=1e-2)
+        p = p0.to(cuda); buf = torch.zeros_like(p); scr = torch.zeros(2, dtype=torch.float64, device=cuda)
+        for step in range(1, 4):
+            gr = torch.randn(n, generator=g)
+            pr.grad = gr.clone()
+            if max_norm:
+                torch.nn.utils.clip_grad_norm_([pr], max_norm)
+            opt.step()
+            gd = gr.to(cuda)
+            L.check(L.lib().uwm_sgd(C.c_void_p(p.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(buf.data_ptr()), n, 1e-2, 0.9,
+                                    1e-2, step, 1.0, max_norm, C.c_void_p(scr.data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            assert (p.cpu() - pr.detach()).abs().max() < 2e-6, (max_norm, step)
+    from oracle import unet_oracle as O
+    torch.manual_seed(0)
+    m = U.Unet("resnet18").to(cuda)
+    tr = Trainer(m, lr=5e-2, optimizer="SGD")
+    assert isinstance(tr.opt, FusedSGD)
+    x, t = O.synthetic_batch(4, 64, 64, seed=3)
+    l0 = float(tr.step(x.to(cuda), t.to(cuda))[0])
+    for _ in range(5):
+        l1 = float(tr.step(x.to(cuda), t.to(cuda))[0])
+    assert l1 < l0
+    with pytest.raises(ValueError):
+        Trainer(m, optimizer="RMSprop")
 
 
 def test_device_input_pipeline_matches_reference_transform(cuda):

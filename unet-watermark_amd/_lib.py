@@ -59,6 +59,7 @@ SIGNATURES = {
     "uwm_stage_range": (I, [P, I, C.POINTER(L), C.POINTER(L)]),
     "uwm_bind": (I, [P, P, P, P]),
     "uwm_workspace_bytes": (Z, [P, I, I, I, I]),
+    "uwm_conv_flops": (I, [P, I, I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "uwm_forward": (I, [P, P, P, P, Z, I, I, I, I, P]),
     "uwm_backward": (I, [P, P, P, I, I, P]),
     "uwm_loss": (I, [P, I, P, I, L, F, F, F, F, P, P, P, I, F, P]),
@@ -66,8 +67,13 @@ SIGNATURES = {
     "uwm_threshold": (I, [P, I, L, F, I, P, P]),
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
     "uwm_adam_clip": (I, [P, P, P, P, L, F, F, F, F, F, L, F, F, P, P]),
+    "uwm_sgd": (I, [P, P, P, L, F, F, F, L, F, F, P, P]),
     "uwm_scale": (I, [P, L, F, P]),
     "uwm_set_winograd": (I, [I]),
+    "uwm_set_winograd_mode": (I, [P, I]),
+    "uwm_get_winograd_mode": (I, [P]),
+    "uwm_allreduce_grads": (I, [P, P, I, I, P]),
+    "uwm_grad_arena": (P, [P]),
     "uwm_set_join_stream": (I, [P, P]),
     "uwm_set_drop_connect": (I, [P, P]),
     "uwm_op_depthwise": (I, [I, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P]),
@@ -161,6 +167,26 @@ def check(rc: int, exc=RuntimeError):
 def stream_ptr(device=None) -> int:
     import torch
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def on_device(t):
+    """Context that makes `t`'s HIP device current for a launch through the free ABI functions (they enqueue on the
+    caller's stream and expect its device to be current); free when it already is."""
+    import torch
+    if t.device.type == "cuda" and t.device.index is not None and t.device.index != torch.cuda.current_device():
+        return torch.cuda.device(t.device)
+    return _NOGUARD
 
 
 _DT = None

@@ -1,7 +1,7 @@
 """`python main.py train|predict ...` — counterpart of the reference's CLI for the model path
 (/root/reference/src/cli.py:368-395 flag names; train loop order /root/reference/src/train.py:207-499:
-epochs of train_epoch + validate (val batch = 2x train batch, :254), ReduceLROnPlateau on the val loss
-(:280-296,408-412), best / periodic checkpoints (:428-460), early stopping (:37-66,413-420)).
+epochs of train_epoch + validate (val batch = 2x train batch, :254), Adam | SGD (:265-279), ReduceLROnPlateau on the
+val loss | CosineAnnealingLR (:280-296,408-412), best / periodic checkpoints (:428-460), early stopping (:37-66,362-368)).
 `repair` / `auto` (IOPaint, OCR, video, data synthesis) are out of scope (SURVEY.md §2 rows 6,9,10).
 Multi-GPU: launch with torch.distributed.run; every rank trains its shard, gradients are all-reduced."""
 from __future__ import annotations
@@ -64,6 +64,52 @@ def _validate(model, loader, criterion, device):
     return tot / nb, {k: v / nb for k, v in agg.items()}
 
 
+class EarlyStopping:
+    """/root/reference/src/train.py:37-66 (patience, min_delta, restore_best_weights) with the shallow-copy quirk fixed
+    (real clones).  Every rank holds one and feeds it the SAME (all-reduced) validation loss, so the
+    stop decision is rank-consistent by construction."""
+
+    def __init__(self, patience=7, min_delta=0.0, restore_best_weights=True):
+        self.patience, self.min_delta, self.restore = int(patience), float(min_delta), restore_best_weights
+        self.best_loss, self.counter, self.best_weights = None, 0, None
+
+    def __call__(self, val_loss, model) -> bool:
+        if self.best_loss is None or val_loss < self.best_loss - self.min_delta:
+            if self.best_loss is not None:
+                self.counter = 0
+            self.best_loss = val_loss
+            if self.restore:
+                self.best_weights = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            self.counter += 1
+        if self.counter >= self.patience:
+            if self.restore and self.best_weights is not None:
+                model.load_state_dict(self.best_weights)
+            return True
+        return False
+
+
+def _rank_mean(value: float, device, world: int) -> float:
+    """Mean over ranks of a host scalar (each rank validates with its own BatchNorm running statistics — the reference
+    has no SyncBN — so per-rank validation losses differ slightly; every decision below uses this ONE number)."""
+    if world <= 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / world
+
+
+def _make_scheduler(cfg, opt):
+    """/root/reference/src/train.py:280-296"""
+    name = cfg.OPTIMIZER.LR_SCHEDULER
+    if name == "ReduceLROnPlateau":
+        return torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=float(cfg.OPTIMIZER.SCHEDULER_FACTOR),
+                                                          patience=int(cfg.OPTIMIZER.SCHEDULER_PATIENCE))
+    if name == "CosineAnnealingLR":
+        return torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=int(cfg.TRAIN.EPOCHS))
+    return None
+
+
 def train_command(args):
     cfg = get_cfg_defaults()
     if args.config and os.path.exists(args.config):
@@ -80,8 +126,16 @@ def train_command(args):
         cfg.MODEL.ENCODER_NAME = args.encoder
     if getattr(args, "model", None):
         cfg.MODEL.NAME = args.model
+    if getattr(args, "optimizer", None):
+        cfg.OPTIMIZER.NAME = args.optimizer
+    if getattr(args, "lr_scheduler", None):
+        cfg.OPTIMIZER.LR_SCHEDULER = args.lr_scheduler
+    if getattr(args, "checkpoint_dir", None):
+        cfg.TRAIN.CHECKPOINT_DIR = args.checkpoint_dir
     if cfg.MODEL.NAME not in ("Unet", "UnetPlusPlus"):
         raise ValueError(f"MODEL.NAME={cfg.MODEL.NAME!r}: this build serves 'Unet' and 'UnetPlusPlus'")
+    if cfg.OPTIMIZER.NAME not in ("Adam", "SGD"):
+        raise ValueError(f"unsupported optimizer: {cfg.OPTIMIZER.NAME}")           # /root/reference/src/train.py:279
     if cfg.MODEL.ENCODER_WEIGHTS is not None:
         print(f"note: ENCODER_WEIGHTS={cfg.MODEL.ENCODER_WEIGHTS!r} needs a download; training from seeded init")
         cfg.MODEL.ENCODER_WEIGHTS = None
@@ -90,32 +144,48 @@ def train_command(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("training needs a HIP device (this path has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("UWM_DIST_BACKEND", "nccl")      # tests: "gloo" lets several ranks share one GPU (RCCL refuses that)
+    if backend == "gloo":
+        local = local % max(1, ndev)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    own_group = False
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+        own_group = True
     torch.manual_seed(int(cfg.DATA.SEED))
     model = create_model_from_config(cfg).to(device)
     wd, wb = _loss_weights(cfg)
     trainer = Trainer(model, w_dice=wd, w_bce=wb, smooth=float(cfg.LOSS.SMOOTH), lr=float(cfg.TRAIN.LR),
-                      weight_decay=float(cfg.TRAIN.WEIGHT_DECAY),
+                      weight_decay=float(cfg.TRAIN.WEIGHT_DECAY), optimizer=cfg.OPTIMIZER.NAME,
                       max_grad_norm=(float(cfg.TRAIN.GRADIENT_CLIP) if args.grad_clip else None))
     criterion = get_loss_function(cfg)
+    sched = _make_scheduler(cfg, trainer.opt)
     start_epoch, best = 0, float("inf")
+    tr_losses, va_losses, tr_hist, va_hist = [], [], [], []
     if args.resume:
         ck = load_checkpoint(args.resume, model, trainer.opt)
+        if sched is not None and ck.get("scheduler_state_dict"):
+            sched.load_state_dict(ck["scheduler_state_dict"])
         start_epoch = int(ck.get("epoch", 0))            # stored epoch is already +1 (Appendix B.9)
-        best = ck.get("best_val_loss", ck.get("val_loss")) or best
-    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(trainer.opt, mode="min", factor=float(cfg.OPTIMIZER.SCHEDULER_FACTOR),
-                                                       patience=int(cfg.OPTIMIZER.SCHEDULER_PATIENCE))
+        b = ck.get("best_val_loss", ck.get("val_loss"))
+        best = float(b) if b is not None else best
+        tr_losses, va_losses = list(ck.get("train_losses", [])), list(ck.get("val_losses", []))
+        tr_hist, va_hist = list(ck.get("train_metrics_history", [])), list(ck.get("val_metrics_history", []))
+        if world > 1:                                    # every rank read the file; make the replicas bit-identical anyway
+            from .train import broadcast_model
+            broadcast_model(model, 0)
+    stopper = (EarlyStopping(patience=int(cfg.TRAIN.EARLY_STOPPING_PATIENCE), restore_best_weights=True)
+               if cfg.TRAIN.USE_EARLY_STOPPING else None)       # /root/reference/src/train.py:362-368
     tr_set, va_set = _datasets(cfg, args.synthetic)
     bs = int(cfg.TRAIN.BATCH_SIZE)
     sampler = DistributedSampler(tr_set, world, rank, shuffle=True, seed=int(cfg.DATA.SEED)) if world > 1 else None
     tr = DataLoader(tr_set, bs, shuffle=sampler is None, sampler=sampler, num_workers=int(args.workers), drop_last=True,
                     pin_memory=True)
     va = DataLoader(va_set, bs * 2, shuffle=False, num_workers=int(args.workers), pin_memory=True)
-    hist, bad = [], 0
+    hist = []
     for epoch in range(start_epoch, int(cfg.TRAIN.EPOCHS)):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -127,26 +197,39 @@ def train_command(args):
             seen += x.shape[0]
         torch.cuda.synchronize(device)
         dt = time.time() - t0
-        tl = float(acc[0]) / max(1, len(tr))
-        vl, vm = _validate(model, va, criterion, device)
-        sched.step(vl)
+        tl = _rank_mean(float(acc[0]) / max(1, len(tr)), device, world)
+        vl_local, vm = _validate(model, va, criterion, device)
+        # ONE validation loss for every rank: LR schedule, best-model bookkeeping and early stopping all read it, so
+        # the replicas take the same decisions and nobody leaves the collective early
+        vl = _rank_mean(vl_local, device, world)
+        vm = {k: _rank_mean(v, device, world) for k, v in sorted(vm.items())}
+        if sched is not None:
+            if cfg.OPTIMIZER.LR_SCHEDULER == "ReduceLROnPlateau":
+                sched.step(vl)
+            else:
+                sched.step()
+        tr_losses.append(tl); va_losses.append(vl); tr_hist.append({}); va_hist.append(vm)
         rec = dict(epoch=epoch + 1, train_loss=tl, val_loss=vl, val_metrics=vm, lr=trainer.opt.param_groups[0]["lr"],
                    images_per_sec=world * seen / max(dt, 1e-9))
         hist.append(rec)
-        if rank == 0:
+        improved = vl < best
+        if improved:
+            best = vl                                       # on EVERY rank
+        if rank == 0:                                       # rank 0's BatchNorm buffers are the ones saved
             print(json.dumps(rec), flush=True)
-            if vl < best:
-                best = vl
+            if improved:
                 save_checkpoint(cfg.TRAIN.MODEL_SAVE_PATH, model, epoch + 1, vl, vm, cfg)
             interval = max(5, int(cfg.TRAIN.EPOCHS) // 10)
             if (epoch + 1) % interval == 0 or epoch >= int(cfg.TRAIN.EPOCHS) - 3:
                 save_checkpoint(os.path.join(cfg.TRAIN.CHECKPOINT_DIR, f"checkpoint_epoch_{epoch + 1:03d}.pth"), model,
                                 epoch + 1, vl, vm, cfg, optimizer=trainer.opt, scheduler=sched, train_loss=tl,
-                                best_val_loss=best, history=hist)
-        bad = 0 if vl <= best else bad + 1
-        if cfg.TRAIN.USE_EARLY_STOPPING and bad >= int(cfg.TRAIN.EARLY_STOPPING_PATIENCE):
+                                train_metrics={}, best_val_loss=best, train_losses=tr_losses, val_losses=va_losses,
+                                train_metrics_history=tr_hist, val_metrics_history=va_hist)
+        if stopper is not None and stopper(vl, model):
+            if rank == 0:
+                print(json.dumps({"early_stop": epoch + 1, "best_val_loss": stopper.best_loss}), flush=True)
             break
-    if world > 1:
+    if own_group:
         dist.destroy_process_group()
     return hist
 
@@ -195,6 +278,9 @@ def main(argv=None):
     tp.add_argument("--workers", type=int, default=2)
     tp.add_argument("--model", choices=["Unet", "UnetPlusPlus"], default=None, help="MODEL.NAME (reference default: UnetPlusPlus)")
     tp.add_argument("--grad-clip", action="store_true", help="honour TRAIN.GRADIENT_CLIP (the reference defines but never applies it)")
+    tp.add_argument("--optimizer", choices=["Adam", "SGD"], default=None, help="OPTIMIZER.NAME")
+    tp.add_argument("--lr-scheduler", choices=["ReduceLROnPlateau", "CosineAnnealingLR", "none"], default=None, help="OPTIMIZER.LR_SCHEDULER")
+    tp.add_argument("--checkpoint-dir", type=str, default=None, help="TRAIN.CHECKPOINT_DIR")
     pp = sub.add_parser("predict")
     pp.add_argument("--input", type=str, required=True); pp.add_argument("--output", type=str, required=True)
     pp.add_argument("--model", type=str, required=True); pp.add_argument("--config", type=str, default=None)

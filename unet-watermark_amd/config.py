@@ -1,9 +1,9 @@
 """Configuration: the reference's yacs tree (/root/reference/src/configs/config.py:8-96) restated with
 PyYAML + attribute nodes (yacs is not in this image).  Same keys, same YAML files; keys the reference
 defines but never reads are accepted, and the loss weights are honoured.
-Defaults differ from the reference in two places only, because this build serves ONE architecture and has
-no network: MODEL.NAME = "Unet" (reference default "UnetPlusPlus") and MODEL.ENCODER_WEIGHTS = None
-(reference default "imagenet", a download)."""
+Defaults are the reference's (MODEL.NAME = "UnetPlusPlus", /root/reference/src/configs/config.py:15) with one
+exception, because this build has no network: MODEL.ENCODER_WEIGHTS = None (reference default "imagenet", a
+download).  BASELINE.json's configs name "Unet": bench.py and the tests pass the architecture explicitly."""
 from __future__ import annotations
 
 import copy
@@ -34,7 +34,7 @@ def _node(d):
 
 _DEFAULTS = {
     "DEVICE": "cuda",
-    "MODEL": dict(NAME="Unet", ENCODER_NAME="resnet34", ENCODER_WEIGHTS=None, ENCODER_DEPTH=5,
+    "MODEL": dict(NAME="UnetPlusPlus", ENCODER_NAME="resnet34", ENCODER_WEIGHTS=None, ENCODER_DEPTH=5,
                   DECODER_CHANNELS=[256, 128, 64, 32, 16], IN_CHANNELS=3, CLASSES=1, ACTIVATION=None),
     "DATA": dict(ROOT_DIR="data/train", ADDITIONAL_ROOT_DIRS=[], IMG_SIZE=512, GENERATE_MASK_THRESHOLD=30,
                  TRAIN_RATIO=0.8, VAL_RATIO=0.2, SHUFFLE=True, SEED=42, NUM_WORKERS=4, CACHE_IMAGES=False,

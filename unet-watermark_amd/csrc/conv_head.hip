@@ -167,10 +167,8 @@ template <int CQ>
 static hipError_t launch_head_dgrad(const ConvArgs& a, hipStream_t st) {
   const int nbands = (a.Ho + 3) / 4;
   const dim3 g((unsigned)(((size_t)nbands * a.Wo * CQ + 255) / 256), (unsigned)a.N);
-  if (prof_on()) prof_begin(30, a.flops, st);
-  if (a.live_ch == 1) hipLaunchKernelGGL((conv_head_dgrad_kernel<CQ, 1>), g, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_head_dgrad_kernel<CQ, 4>), g, dim3(256), 0, st, a);
-  if (prof_on()) prof_end(st);
+  if (a.live_ch == 1) UWM_LAUNCH(30, a.flops, a.bytes, (conv_head_dgrad_kernel<CQ, 1>), g, dim3(256), 0, st, a);
+  else UWM_LAUNCH(30, a.flops, a.bytes, (conv_head_dgrad_kernel<CQ, 4>), g, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_conv_head_dgrad(const ConvArgs& a, hipStream_t st) {
@@ -192,10 +190,8 @@ template <int CQ>
 static hipError_t launch_head(const ConvArgs& a, hipStream_t st) {
   const int nbands = (a.Ho + 3) / 4;
   const dim3 g((unsigned)(((size_t)nbands * a.Wo * CQ + 255) / 256), (unsigned)a.N);
-  if (prof_on()) prof_begin(30, a.flops, st);
-  if (a.wrows == 1) hipLaunchKernelGGL((conv_head_kernel<CQ, 1>), g, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_head_kernel<CQ, 4>), g, dim3(256), 0, st, a);
-  if (prof_on()) prof_end(st);
+  if (a.wrows == 1) UWM_LAUNCH(30, a.flops, a.bytes, (conv_head_kernel<CQ, 1>), g, dim3(256), 0, st, a);
+  else UWM_LAUNCH(30, a.flops, a.bytes, (conv_head_kernel<CQ, 4>), g, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -261,15 +261,9 @@ template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -283,12 +277,8 @@ static hipError_t launch_s2_dgrad(const ConvArgs& a0, hipStream_t st, int cls) {
   const int Mg = a0.N * (a0.Ho >> 1) * (a0.Wo >> 1);
   const int tilesM = (Mg + BM - 1) / BM, tilesN = (a0.Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN, true>, lds); if (e != hipSuccess) return e; }
   ConvArgs a = a0;
   for (int pc = 0; pc < 4; ++pc) {
     a.pc_taps[pc] = 0; a.pc_ntaps[pc] = 0;
@@ -296,9 +286,7 @@ static hipError_t launch_s2_dgrad(const ConvArgs& a0, hipStream_t st, int cls) {
       for (int s = 0; s < a.kw; ++s)         // tap (r, s) reaches an input pixel iff (ho - r + off) and (wo - s + off) are even
         if (((((pc >> 1) - r + a.off) | ((pc & 1) - s + a.off)) & 1) == 0) { a.pc_taps[pc] |= (unsigned)(r * a.kw + s) << (4 * a.pc_ntaps[pc]); ++a.pc_ntaps[pc]; }
   }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -307,9 +295,15 @@ bool winograd_enabled() {
   if (g_winograd < 0) { const char* e = getenv("UWM_WINOGRAD"); g_winograd = (e && e[0] == '0') ? 0 : 1; }
   return g_winograd != 0;
 }
-void winograd_enable(bool on) { g_winograd = on ? 1 : 0; }
 void winograd_set_mode(int mode) { g_winograd = mode; }
 int winograd_mode() { (void)winograd_enabled(); return g_winograd; }
+int device_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return 256;
+  if (!cus[dev] && (hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus[dev] <= 0)) cus[dev] = 256;
+  return cus[dev];
+}
 
 // tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
@@ -319,7 +313,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (trace)
     fprintf(stderr, "conv %s N=%d Ctot=%d(C0=%d up=%d) Cout=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d smul=%d sdiv=%d wino=%d gflop=%.2f\n",
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
-            (int)(cfg < 0 && winograd_enabled() && conv_wino_applicable(a)), a.flops * 1e-9);
+            (int)(cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)), a.flops * 1e-9);
   if (cfg == 500) return launch_conv_head(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
   if (a.out_up) return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;   // fused concat split: Winograd epilogue only
@@ -328,7 +322,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);
   if (cfg < 0 && !no_head && conv_head_dgrad_applicable(a)) return launch_conv_head_dgrad(a, st);      // few channels -> <= 4 classes: HBM streaming kernel
   // 16-channel inputs at full resolution are HBM-bound: the one-barrier direct kernel beats the Winograd pipeline there
-  if (cfg < 0 && winograd_enabled() && conv_wino_applicable(a) && !conv_patch16_applicable(a)) return launch_conv_wino(a, st);
+  if (cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a)) return launch_conv_wino(a, st);
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);
   if (cfg < 0 && conv_patch16_applicable(a)) return launch_conv_patch16(a, st);
   if (cfg < 0 && conv_patch_applicable(a)) {

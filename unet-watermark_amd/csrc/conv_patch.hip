@@ -269,15 +269,9 @@ static hipError_t launch_p(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesN = (a.Cout + BN - 1) / BN;
   const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
   const size_t lds = (size_t)(kPP * 32 + 2 * BN * 32) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_patch_kernel<BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((conv_patch_kernel<BN, WM, WN>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_patch_kernel<BN, WM, WN>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_patch_kernel<BN, WM, WN>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

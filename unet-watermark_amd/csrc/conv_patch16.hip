@@ -167,9 +167,7 @@ static hipError_t launch_p16(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesN = (a.Cout + BN - 1) / BN;
   const int tilesW = (a.Wo + kT - 1) / kT, tilesH = (a.Ho + kT - 1) / kT;
   const size_t lds = (size_t)(kPPix * 16 + BN * kWLd) * sizeof(float);
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((conv_patch16_kernel<BN>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_patch16_kernel<BN>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -415,15 +415,9 @@ static hipError_t launch_w(const ConvArgs& a, hipStream_t st, int cls) {
   const size_t main_lds = (size_t)2 * (2 * kPlane + 16 * NI * 128) * sizeof(float);
   const size_t q_lds = (size_t)4 * 2 * 32 * (BN + kQPad) * sizeof(float);
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel<NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((conv_wino_kernel<NI>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_wino_kernel<NI>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_wino_kernel<NI>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -278,8 +278,8 @@ bool conv_wino8_applicable(const ConvArgs& a) {
   // Measured (r01): 3-5 % faster than conv_wino_kernel<4> launch for launch, but its 87-KB / 512-thread workgroups
   // co-reside worse with the weight-gradient kernels of the side stream: with EVERY eligible launch on it the
   // overlapped train step is 2 % slower (580 vs 590 img/s).  So: forward convolutions only (nothing runs beside them),
-  // dgrads stay on the 4-wave kernel; uwm_set_winograd(2) / force_cfg 308 select it wherever the shape allows.
-  if (winograd_mode() == 2) return true;
+  // dgrads stay on the 4-wave kernel; Winograd mode 2 / force_cfg 308 select it wherever the shape allows.
+  if (wino_mode_of(a.wino) == 2) return true;
   const long wgs = (long)a.N * ((a.Ho + kT8 - 1) / kT8) * ((a.Wo + kT8 - 1) / kT8) * ((a.Cout + 63) / 64);
   return a.rmul == 1 && wgs >= 256;      // one 512-thread workgroup per CU: fewer would leave CUs idle
 }
@@ -291,15 +291,9 @@ hipError_t launch_conv_wino8(const ConvArgs& a, hipStream_t st) {
   const size_t main_lds = (size_t)(2 * kUs8 + 2 * kPb8) * sizeof(float);
   const size_t q_lds = (size_t)4 * 64 * kQLD8 * sizeof(float);
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(25, a.flops, st);
-  hipLaunchKernelGGL(conv_wino8_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(512), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_wino8_kernel, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(25, a.flops, a.bytes, conv_wino8_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 

@@ -530,6 +530,39 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, f
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ SGD with momentum (torch.optim.SGD: coupled L2, dampening 0, no Nesterov)
+// g' = g*gscale + wd*p ; buf = first ? g' : momentum*buf + g' ; p -= lr*buf
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n4, size_t n, float lr,
+                           float momentum, float wd, int first, float gscale, const double* sumsq, float max_norm) {
+  if (sumsq) {
+    const float tn = (float)sqrt(*sumsq) * gscale;
+    gscale *= fminf(1.f, max_norm / (tn + 1e-6f));
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = i * 4;
+    if (o + 4 <= n) {
+      f4 pv = *(f4*)(p + o), gv = *(const f4*)(g + o) * gscale;
+      gv += wd * pv;
+      f4 bv = gv;
+      if (!first) bv = momentum * *(f4*)(buf + o) + gv;
+      pv -= lr * bv;
+      *(f4*)(p + o) = pv; *(f4*)(buf + o) = bv;
+    } else {
+      for (size_t j = o; j < n; ++j) {
+        const float gj = g[j] * gscale + wd * p[j];
+        const float bj = first ? gj : momentum * buf[j] + gj;
+        p[j] -= lr * bj; buf[j] = bj;
+      }
+    }
+  }
+}
+hipError_t launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, float gscale,
+                      hipStream_t st, const double* sumsq, float max_norm) {
+  const size_t n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(sgd_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, p, g, buf, n4, n, lr, momentum, wd, first, gscale, sumsq, max_norm);
+  return hipGetLastError();
+}
+
 // sum of squares of a flat range (global gradient norm), fp64 across workgroups
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, size_t n, double* out) {
   float acc = 0.f;
@@ -563,7 +596,7 @@ hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ HIP-event profiler (host side)
-struct ProfRec { int cls; double flops; hipEvent_t e0, e1; };
+struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -573,19 +606,18 @@ static hipEvent_t prof_event() {
 }
 void prof_enable(bool on) { g_prof = on; }
 bool prof_on() { return g_prof; }
-void prof_begin(int cls, double flops, hipStream_t st) {
-  ProfRec r; r.cls = cls; r.flops = flops; r.e0 = prof_event(); r.e1 = prof_event();
-  (void)hipEventRecord(r.e0, st);
+void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+  ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.e0 = prof_event(); r.e1 = prof_event();
+  *e0 = r.e0; *e1 = r.e1;
   g_recs.push_back(r);
 }
-void prof_end(hipStream_t st) { if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, st); }
 int prof_collect(double* out) {
-  for (int i = 0; i < kProfClasses * 3; ++i) out[i] = 0.0;
+  for (int i = 0; i < kProfClasses * 4; ++i) out[i] = 0.0;
   for (auto& r : g_recs) {
     (void)hipEventSynchronize(r.e1);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess && r.cls >= 0 && r.cls < kProfClasses) {
-      out[r.cls * 3 + 0] += 1.0; out[r.cls * 3 + 1] += (double)ms; out[r.cls * 3 + 2] += r.flops;
+      out[r.cls * 4 + 0] += 1.0; out[r.cls * 4 + 1] += (double)ms; out[r.cls * 4 + 2] += r.flops; out[r.cls * 4 + 3] += r.bytes;
     }
     g_pool.push_back(r.e0); g_pool.push_back(r.e1);
   }

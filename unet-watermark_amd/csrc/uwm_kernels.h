@@ -6,6 +6,7 @@
 //   the CONSUMER when it stages the tile (BatchNorm-apply + ReLU never make their own pass)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -27,6 +28,21 @@ static inline FastDiv make_fastdiv(unsigned d) {
   FastDiv f; f.d = d; f.mg = (d <= 1) ? 0u : (unsigned)((0x100000000ull / d) + 1ull); return f;
 }
 
+// ---- per-device launch state.  hipFuncSetAttribute and the CU count belong to a DEVICE, not to the process: one flag
+// per (kernel instantiation, device), so a process that drives several GPUs sets the attribute on each of them.
+struct DevOnce {
+  unsigned long long mask = 0;
+  hipError_t set_max_lds(const void* fn, size_t bytes) {
+    int dev = 0; hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) mask |= 1ull << dev;
+    return e;
+  }
+};
+int device_cu_count();       // compute units of the CURRENT device (cached per device)
+
 struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (transposed gather)
   Src s0, s1;                // channel-concat of two sources: [0,C0) from s0, [C0,Ctot) from s1
   int C0, Ctot;
@@ -44,6 +60,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int srep, sstride;         // statistics replicas: workgroup b adds into copy (b & (srep-1)) at +copy*sstride doubles (srep: power of 2, 0/1 = none)
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
+  double bytes;              // algorithmic HBM bytes of this launch: every operand read once + the output written once (profiling only)
   // decoder dgrad with the concat split fused into the epilogue (conv_wino.hip only): output channels [0, up_c0) are
   // summed over each 2x2 pixel block (nearest-x2 upsample backward), ReLU-masked by the low-resolution producer
   // (up_mask * up_mscale + up_mshift > 0) and written to out_up [N][Ho/2][Wo/2][up_c0]; channels [up_c0, Cout) go to
@@ -54,6 +71,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int live_ch;               // dgrad: channels of dY that can be non-zero (0 = all; the head's classes inside its 4 padded channels)
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
+  int wino;                  // Winograd mode of this launch: 0 = process default (uwm_set_winograd), else mode + 1 (per-handle: uwm_set_winograd_mode)
 };
 
 struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = tap*Ctot + c)
@@ -67,6 +85,8 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   int force_igemm;           // tests: 1 = never route to wgrad_patch
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
+  double bytes;              // algorithmic HBM bytes of this launch: every operand read once + the output written once (profiling only)
+  int wino;                  // as ConvArgs::wino
 };
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
@@ -75,9 +95,20 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 enum { kProfClasses = 31 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
-void prof_begin(int cls, double flops, hipStream_t st);
-void prof_end(hipStream_t st);
-int  prof_collect(double* out /* [kProfClasses][3] = launches, ms, flops */);
+void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
+// One profiled launch = one (start, stop) event pair attached to the KERNEL DISPATCH itself (hipExtLaunchKernelGGL): the
+// pair carries the dispatch's own begin / end timestamps — the clock rocprofv3's kernel trace reads — so a launch that
+// waits for CUs behind the other stream's kernels is not charged for the wait (events recorded AROUND the launch were).
+#define UWM_LAUNCH(cls, flops, bytes, kernel, grid, block, lds, st, ...)                                     \
+  do {                                                                                                       \
+    if (prof_on()) {                                                                                         \
+      hipEvent_t e0_, e1_; prof_pair((cls), (flops), (bytes), &e0_, &e1_);                                   \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0_, e1_, 0, __VA_ARGS__);                         \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                         \
+    }                                                                                                        \
+  } while (0)
+int  prof_collect(double* out /* [kProfClasses][4] = launches, ms, flops, bytes */);
 const char* prof_class_name(int cls);
 
 // ---- launchers (all asynchronous on `st`, no host sync, no allocation) ----
@@ -109,10 +140,12 @@ hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, in
 struct WinoJob { const float* w; float* ut; int rows, chans, Kpad, mode, src_rows, pad_; };
 struct WinoJobs { WinoJob j[40]; int n; };
 hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st);   // every layer's transform in one launch
+// process default (UWM_WINOGRAD / uwm_set_winograd): used by the single-operator entry points and by handles created later
 bool winograd_enabled();
-void winograd_enable(bool on);
 void winograd_set_mode(int mode);   // 0 off, 1 auto, 2 = tests: take the 8-wave variant wherever its shape rules allow
 int winograd_mode();
+// mode of ONE launch: the handle's own mode when its args carry one (wino = mode + 1), else the process default
+static inline int wino_mode_of(int wino) { return wino > 0 ? wino - 1 : winograd_mode(); }
 
 hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t st);
 hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float* gamma, const float* beta,
@@ -150,6 +183,8 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, f
                        float eps, float wd, float bc1, float bc2, float gscale, hipStream_t st,
                        const double* sumsq = nullptr, float max_norm = 0.f);
 hipError_t launch_sumsq(const float* g, size_t n, double* out, hipStream_t st);
+hipError_t launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, float gscale,
+                      hipStream_t st, const double* sumsq = nullptr, float max_norm = 0.f);
 hipError_t launch_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float thr,
                                    int apply_sigmoid, uint8_t* out, float* out_f, hipStream_t st);
 hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st);

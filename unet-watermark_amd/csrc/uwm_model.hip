@@ -8,6 +8,7 @@
 #include "uwm_kernels.h"
 
 #include <cstdarg>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -66,7 +67,8 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   size_t x4 = 0, pool = 0, pool_idx = 0, g_pool = 0, tmp = 0, loss_scr = 0;
   std::vector<size_t> y, g;         // per conv: raw output / its gradient buffer (float offsets)
   std::vector<int> oh, ow;          // per conv: output height / width
-  bool wino_ok(size_t ci) const { return winograd_enabled() && oh[ci] >= 8 && ow[ci] >= 16; }   // conv_wino tile fits
+  int wino_mode = 1;                // the handle's Winograd mode when this plan was made (0 off, 1 auto, 2 = 8-wave variant wherever allowed)
+  bool wino_ok(size_t ci) const { return wino_mode != 0 && oh[ci] >= 8 && ow[ci] >= 16; }   // conv_wino tile fits
   std::vector<size_t> xn, gx;       // per encoder block: residual output / its gradient
   std::vector<size_t> dcat, gskip;  // per decoder block (UnetPlusPlus: dcat[0] = shared scratch, gskip[0..3] = f4,f3,f2,f1 accumulators)
   size_t stem_a = 0;                // EfficientNet: materialised stem feature f1 = swish(bn(conv_stem))
@@ -109,7 +111,11 @@ struct uwm_model {
   int use_side = 1;
   hipStream_t join_stream = nullptr;  // uwm_set_join_stream: stream that waits for the side stream at the end of uwm_backward (default: the caller's)
   bool packed_in_fwd = false;         // dgrad weight repacks were enqueued on the side stream by the last forward
-  int pack_mode = -1;                 // uwm_set_winograd mode those repacks were made for
+  int pack_mode = -1;                 // Winograd mode those repacks were made for
+  int wino_mode = 1;                  // per-handle Winograd mode (uwm_set_winograd_mode); starts as the process default
+  int device = -1;                    // HIP device the bound arenas live on (uwm_bind)
+  int nstages = 5;                    // backward stages = gradient buckets (head+decoder, then four encoder groups)
+  bool hwq_warned = false;
 };
 
 static int add_bn(uwm_model* m, const std::string& name, int C, int stage, float eps = 0.f, float mom = 0.f) {
@@ -325,7 +331,7 @@ static int build_model(uwm_model* m) {
 
 // ------------------------------------------------------------------------------ workspace plan
 static void make_plan(uwm_model* m, int N, int H, int W, int training) {
-  Plan p; p.N = N; p.H = H; p.W = W; p.training = training;
+  Plan p; p.N = N; p.H = H; p.W = W; p.training = training; p.wino_mode = m->wino_mode;
   size_t off = m->fixed_floats;
   auto alloc = [&](size_t floats) { size_t o = off; off += (size_t)rup((long long)floats, 64); return o; };
   const size_t nc = m->convs.size();
@@ -490,7 +496,10 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
+  a.bytes = 4.0 * ((double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) + (double)cv.Cout * cv.Kpad +
+                   (double)a.M * cv.CoutP);
   if (cv.wu_off && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout); }
+  a.wino = c.m->plan.wino_mode + 1;
   return launch_conv(a, c.st, cfg);
 }
 
@@ -508,7 +517,10 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift; a.live_ch = cv.Cout;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
+  a.bytes = 4.0 * ((double)c.N * Ho * Wo * cv.CoutP + (double)cv.CinP * cv.KpadD +
+                   (double)a.M * cv.CinP * (1.0 + (addend ? 1.0 : 0.0) + (mask ? 1.0 : 0.0)));
   if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
+  a.wino = c.m->plan.wino_mode + 1;
   if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
   return launch_conv(a, c.st);
 }
@@ -523,6 +535,9 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.Hl = s0.H << s0.up; a.Wl = s0.W << s0.up; a.stride = cv.stride; a.pad = cv.pad;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
+  a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
+                   (double)cv.Cout * cv.Kpad);
+  a.wino = c.m->plan.wino_mode + 1;
   if (c.wst && c.wst != c.st) {
     // fork: the side stream must see everything enqueued so far on the main stream (dy, activations)
     hipError_t e = hipEventRecord(c.m->ev_fork, c.st);
@@ -572,7 +587,7 @@ static hipError_t run_bn_bwd_act(const Ctx& c, int ci, const float* g, float* dy
 // Winograd filter transforms of every eligible layer (forward banks, or dgrad banks straight from the forward
 // weights), at most 40 layers per launch
 static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
-  if (!winograd_enabled()) return hipSuccess;
+  if (c.m->plan.wino_mode == 0) return hipSuccess;
   WinoJobs jobs; jobs.n = 0;
   const uwm_model* m = c.m;
   for (size_t ci = 0; ci < m->convs.size(); ++ci) {
@@ -592,6 +607,9 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
                       hipStream_t st) {
   const Plan& p = m->plan;
   Ctx c{m, ws, st, N};
+  // a previous training forward that was never followed by a backward left its dgrad repacks on the side stream with
+  // nothing joined to them: this stream must not touch the workspace (re-planned, re-used or re-allocated) before they land
+  if (m->packed_in_fwd) HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
   if (training) HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
   m->packed_in_fwd = false;
   if (training && m->use_side && m->side && m->grads) {
@@ -608,7 +626,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     }
     LCHK(wino_jobs(c, true, m->side));
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
-    m->packed_in_fwd = true; m->pack_mode = winograd_mode();
+    m->packed_in_fwd = true; m->pack_mode = p.wino_mode;
   }
   LCHK(wino_jobs(c, false, st));
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
@@ -782,10 +800,11 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
     HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
     if (p.se_gs_floats) HIPCHK(hipMemsetAsync(c.F(p.se_gs_all), 0, p.se_gs_floats * sizeof(float), st));
-    if (m->packed_in_fwd && m->pack_mode == winograd_mode()) {      // (a mode switch between forward and backward: redo them)
+    if (m->packed_in_fwd && m->pack_mode == p.wino_mode) {      // (a mode switch between forward and backward: redo them)
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
+      m->packed_in_fwd = false;           // joined
     } else {
-      if (m->packed_in_fwd) HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));     // stale packs must have landed before they are overwritten
+      if (m->packed_in_fwd) { HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0)); m->packed_in_fwd = false; }     // stale packs must have landed before they are overwritten
       for (size_t ci = 0; ci < m->convs.size(); ++ci) {
         const ConvL& cv = m->convs[ci];
         if (cv.dgrad && (!(cv.wud_off && p.wino_ok(ci)) || cv.CoutP == 16))
@@ -1027,6 +1046,8 @@ int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
   if (build_model(m)) { delete m; return 1; }
   const char* e = getenv("UWM_SIDE_STREAM");
   m->use_side = e ? atoi(e) : 1;
+  m->wino_mode = winograd_mode();       // process default (UWM_WINOGRAD / uwm_set_winograd) at creation; then per handle
+  m->plan.wino_mode = m->wino_mode;
   *out = m; return 0;
 }
 void uwm_destroy(uwm_handle h) {
@@ -1047,21 +1068,58 @@ int uwm_tensor_info_get(uwm_handle h, int i, uwm_tensor_info* out) {
   *out = h->infos[i]; return 0;
 }
 int uwm_logits_channels(uwm_handle h) { return h ? h->CP : 0; }
-int uwm_num_stages(uwm_handle) { return 5; }
+int uwm_num_stages(uwm_handle h) { return h ? h->nstages : 0; }
 int uwm_stage_range(uwm_handle h, int stage, long long* b, long long* e) {
-  if (!h || stage < 0 || stage >= 5 || !b || !e) return fail("uwm_stage_range: bad stage %d", stage);
+  if (!h || stage < 0 || stage >= h->nstages || !b || !e) return fail("uwm_stage_range: bad stage %d", stage);
   *b = h->stage_begin[stage]; *e = h->stage_begin[stage + 1]; return 0;
 }
+// RAII: make `dev` the current HIP device for the scope of one ABI call (a handle is bound to the device its arenas
+// live on; the caller's current device may be another one)
+struct DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (dev < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); return; }
+    if (prev != dev && hipSetDevice(dev) == hipSuccess) switched = true;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 int uwm_bind(uwm_handle h, float* params, float* grads, float* buffers) {
   if (!h || !params || !buffers) return fail("uwm_bind: params and buffers must be non-null");
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)buffers) & 15) return fail("uwm_bind: arenas must be 16-byte aligned");
+  hipPointerAttribute_t at;
+  int dev = -1;
+  if (hipPointerGetAttributes(&at, params) == hipSuccess) dev = at.device; else (void)hipGetLastError();
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+  if (h->device >= 0 && h->device != dev && h->side) {      // arenas moved to another device: the side stream moves with them
+    DeviceGuard g0(h->device);
+    (void)hipStreamSynchronize(h->side);
+    (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pack);
+    (void)hipStreamDestroy(h->side);
+    h->side = nullptr; h->ev_fork = h->ev_join = h->ev_pack = nullptr; h->packed_in_fwd = false;
+  }
+  h->device = dev;
   h->params = params; h->grads = grads; h->buffers = buffers;
-  if (h->use_side && !h->side) {        // created lazily on the device the arenas live on (current device)
+  DeviceGuard guard(dev);
+  if (h->use_side && !h->side) {        // created on the device the arenas live on
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; (void)hipGetLastError(); }
     else if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(h->side); h->side = nullptr; (void)hipGetLastError();
+    }
+    // ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  In a process that
+    // has already created several streams (RCCL, torch) the side stream can alias the compute stream's queue: the
+    // weight-gradient overlap is then silently lost (measured -5 %).  The variable is read when the HIP
+    // runtime initialises, so all the library can do at this point is say so.
+    if (h->side && !h->hwq_warned) {
+      const char* q = getenv("GPU_MAX_HW_QUEUES");
+      if (!q || atoi(q) < 8) {
+        fprintf(stderr, "libuwm: warning: GPU_MAX_HW_QUEUES=%s (< 8): the weight-gradient side stream may share a hardware queue with "
+                        "the compute stream and lose its overlap; export GPU_MAX_HW_QUEUES=8 before the HIP runtime starts\n", q ? q : "unset");
+        h->hwq_warned = true;
+      }
     }
   }
   return 0;
@@ -1084,6 +1142,24 @@ size_t uwm_workspace_bytes(uwm_handle h, int N, int H, int W, int training) {
   return h->plan.bytes;
 }
 
+// Algorithmic (direct-convolution) FLOPs per IMAGE of this model at H x W — SURVEY.md 8(d)'s roofline numerator:
+// forward = sum over conv layers of 2*Ho*Wo*Cout*Cin_per_group*k*k ; forward+backward = 3x that minus the stem's dgrad
+// (the input image needs no gradient).  BatchNorm / elementwise / loss / optimizer work is not counted.
+int uwm_conv_flops(uwm_handle h, int H, int W, double* fwd, double* fwd_bwd) {
+  if (!h || !fwd || !fwd_bwd) return fail("uwm_conv_flops: null argument");
+  if (check_shape(1, H, W)) return 1;
+  const Plan keep = h->plan;
+  make_plan(h, 1, H, W, 0);
+  double f = 0.0, fb = 0.0;
+  for (size_t ci = 0; ci < h->convs.size(); ++ci) {
+    const ConvL& cv = h->convs[ci];
+    const double macs = (double)h->plan.oh[ci] * h->plan.ow[ci] * cv.Cout * (cv.dw ? 1 : cv.Cin) * cv.k * cv.k;
+    f += 2.0 * macs; fb += 2.0 * macs * ((int)ci == h->stem ? 2.0 : 3.0);
+  }
+  h->plan = keep;
+  *fwd = f; *fwd_bwd = fb; return 0;
+}
+
 int uwm_forward(uwm_handle h, const float* x, float* logits, void* ws, size_t ws_bytes, int N, int H, int W, int training,
                 uwm_stream stream) {
   if (!h || !x || !logits || !ws) return fail("uwm_forward: null argument");
@@ -1093,6 +1169,7 @@ int uwm_forward(uwm_handle h, const float* x, float* logits, void* ws, size_t ws
   const size_t need = uwm_workspace_bytes(h, N, H, W, training);
   if (ws_bytes < need) return fail("uwm_forward: workspace too small (%zu < %zu bytes)", ws_bytes, need);
   h->have_fwd = false;
+  DeviceGuard guard(h->device);
   if (do_forward(h, x, logits, (float*)ws, N, H, W, training ? 1 : 0, (hipStream_t)stream)) return 1;
   h->have_fwd = training != 0;
   return 0;
@@ -1102,7 +1179,8 @@ int uwm_backward(uwm_handle h, const float* dlogits, void* ws, int sb, int se, u
   if (!h || !dlogits || !ws) return fail("uwm_backward: null argument");
   if (!h->grads) return fail("uwm_backward: no gradient arena bound");
   if (!h->have_fwd) return fail("uwm_backward: no training-mode forward is held in the workspace");
-  if (sb < 0 || se > 5 || sb >= se) return fail("uwm_backward: bad stage range [%d,%d)", sb, se);
+  if (sb < 0 || se > h->nstages || sb >= se) return fail("uwm_backward: bad stage range [%d,%d)", sb, se);
+  DeviceGuard guard(h->device);
   return do_backward(h, dlogits, (float*)ws, sb, se, (hipStream_t)stream);
 }
 
@@ -1143,6 +1221,14 @@ int uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, flo
   LCHK(launch_adam(p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream, (const double*)scratch, max_norm));
   return 0;
 }
+int uwm_sgd(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, long long step, float gscale,
+            float max_norm, void* scratch, uwm_stream stream) {
+  if (!p || !g || !buf || n < 1 || step < 1 || (max_norm > 0.f && !scratch)) return fail("uwm_sgd: bad argument");
+  if (max_norm > 0.f) LCHK(launch_sumsq(g, (size_t)n, (double*)scratch, (hipStream_t)stream));
+  LCHK(launch_sgd(p, g, buf, (size_t)n, lr, momentum, wd, step == 1, gscale, (hipStream_t)stream,
+                  max_norm > 0.f ? (const double*)scratch : nullptr, max_norm));
+  return 0;
+}
 int uwm_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float threshold, int apply_sigmoid,
                          uint8_t* mask, float* resized, uwm_stream stream) {
   if (!logits || (!mask && !resized) || N < 1 || h < 1 || w < 1 || H < 1 || W < 1 || ld < 1) return fail("uwm_resize_threshold: bad argument");
@@ -1177,7 +1263,7 @@ int uwm_set_side_stream(uwm_handle h, int on) {
 // ---- HIP-event profiler (bench.py's roofline leg)
 int uwm_prof_enable(int on) { prof_enable(on != 0); return 0; }
 int uwm_prof_collect(double* out, int max_classes) {
-  if (!out || max_classes < kProfClasses) return fail("uwm_prof_collect: need room for %d classes", (int)kProfClasses);
+  if (!out || max_classes < kProfClasses) return fail("uwm_prof_collect: need room for %d classes (4 doubles each)", (int)kProfClasses);
   prof_collect(out); return kProfClasses;
 }
 const char* uwm_prof_class_name(int cls) { return prof_class_name(cls); }
@@ -1274,6 +1360,45 @@ int uwm_op_depthwise(int mode, const float* a, const float* b, int k, int stride
 }
 long long uwm_op_depthwise_scratch_floats(int k, int N, int C, int Ho, int Wo) { return (long long)dw_wgrad_scratch_floats(k, N, C, Ho, Wo); }
 int uwm_set_winograd(int on) { winograd_set_mode(on < 0 ? 0 : (on > 2 ? 1 : on)); return 0; }
+int uwm_set_winograd_mode(uwm_handle h, int mode) {
+  if (!h) return fail("uwm_set_winograd_mode: null handle");
+  if (mode < 0 || mode > 2) return fail("uwm_set_winograd_mode: mode must be 0 (direct kernels), 1 (auto) or 2 (8-wave variant wherever allowed), got %d", mode);
+  h->wino_mode = mode; h->plan.wino_mode = mode;       // the workspace layout does not depend on the mode
+  return 0;
+}
+int uwm_get_winograd_mode(uwm_handle h) { return h ? h->wino_mode : -1; }
+
+// ---- data-parallel exchange on the C ABI: SUM all-reduce of the gradient arena ranges of backward
+// stages [stage_begin, stage_end) over an RCCL communicator, one collective per stage (= bucket), enqueued on `stream`.
+// RCCL is resolved at run time from the process (the library the caller's communicator came from), never linked.
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static nccl_allreduce_fn g_allreduce = nullptr;
+static int resolve_rccl() {
+  if (g_allreduce) return 0;
+  void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+  if (!sym) {
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib) sym = dlsym(lib, "ncclAllReduce");
+  }
+  if (!sym) return fail("uwm_allreduce_grads: ncclAllReduce not found (load RCCL in the host process first)");
+  g_allreduce = (nccl_allreduce_fn)sym; return 0;
+}
+int uwm_allreduce_grads(uwm_handle h, void* comm, int sb, int se, uwm_stream stream) {
+  if (!h || !comm) return fail("uwm_allreduce_grads: null argument");
+  if (!h->grads) return fail("uwm_allreduce_grads: no gradient arena bound");
+  if (sb < 0 || se > h->nstages || sb >= se) return fail("uwm_allreduce_grads: bad stage range [%d,%d)", sb, se);
+  if (resolve_rccl()) return 1;
+  DeviceGuard guard(h->device);
+  for (int k = sb; k < se; ++k) {
+    const long long b = h->stage_begin[k], e = h->stage_begin[k + 1];
+    if (e <= b) continue;
+    const int rc = g_allreduce(h->grads + b, h->grads + b, (size_t)(e - b), /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, (hipStream_t)stream);
+    if (rc != 0) return fail("uwm_allreduce_grads: ncclAllReduce failed on bucket %d (ncclResult_t %d)", k, rc);
+  }
+  return 0;
+}
+float* uwm_grad_arena(uwm_handle h) { return h ? h->grads : nullptr; }
 static Src to_src(const uwm_src* s) { return mk_src(s->ptr, s->C, s->H, s->W, s->scale, s->shift, s->relu, s->up); }
 
 int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
@@ -1290,7 +1415,7 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
-  if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_enabled())) && op_wino_shape(a, kh, kw, stride, pad)) {
+  if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
     if (op_wino_prepare(a, 0, (hipStream_t)stream)) return 1;
   } else if (cfg >= 300 && cfg < 500) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
   LCHK(launch_conv(a, (hipStream_t)stream, cfg));
@@ -1307,7 +1432,7 @@ int uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* 
   a.Hl = Ho; a.Wl = Wo; a.smul = 1; a.rmul = -1; a.off = pad; a.sdiv = stride;
   a.out = dx; a.addend = addend; a.mask = mask; a.mscale = mscale; a.mshift = mshift;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
-  if (winograd_enabled() && op_wino_shape(a, kh, kw, stride, pad) && op_wino_prepare(a, 1, (hipStream_t)stream)) return 1;
+  if (winograd_mode() != 0 && op_wino_shape(a, kh, kw, stride, pad) && op_wino_prepare(a, 1, (hipStream_t)stream)) return 1;
   LCHK(launch_conv(a, (hipStream_t)stream));
   return 0;
 }

@@ -199,15 +199,9 @@ template <int TA, int TB, int WA, int WB>
 static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
   const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Kpad + TB - 1) / TB;
   const size_t lds = (size_t)2 * 32 * (TA + 16 + TB + 16) * sizeof(float) + 2 * 32 * 4 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_igemm_kernel<TA, TB, WA, WB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((wgrad_igemm_kernel<TA, TB, WA, WB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_igemm_kernel<TA, TB, WA, WB>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_igemm_kernel<TA, TB, WA, WB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -216,10 +210,10 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   static const bool trace = getenv("UWM_TRACE_CONV") != nullptr;
   if (trace)
     fprintf(stderr, "wgrad N=%d Ctot=%d(C0=%d) Cout=%d wrows=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d stride=%d wino=%d patch=%d gflop=%.2f\n", a0.N, a0.Ctot,
-            a0.C0, a0.Cout, a0.wrows, a0.Ho, a0.Wo, a0.Hl, a0.Wl, a0.ntaps, a0.stride, (int)(winograd_enabled() && wgrad_wino_applicable(a0)),
+            a0.C0, a0.Cout, a0.wrows, a0.Ho, a0.Wo, a0.Hl, a0.Wl, a0.ntaps, a0.stride, (int)(wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)),
             (int)wgrad_patch_applicable(a0), a0.flops * 1e-9);
   // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd
-  if ((a0.force_igemm & 0xff) == 0 && winograd_enabled() && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
+  if ((a0.force_igemm & 0xff) == 0 && wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
   if ((a0.force_igemm & 0xff) != 1 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);
   WgradArgs a = a0;
   if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;

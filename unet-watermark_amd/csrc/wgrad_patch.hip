@@ -241,15 +241,9 @@ template <int TA, int CW>
 static hipError_t launch_wp(const WgradArgs& a, hipStream_t st, int cls, int nblocks) {
   size_t lds = (size_t)(2 * 128 * TA + 2 * kPP * CW) * sizeof(float);
   if (lds < (size_t)TA * 9 * CW * sizeof(float)) lds = (size_t)TA * 9 * CW * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_patch_kernel<TA, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((wgrad_patch_kernel<TA, CW>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_patch_kernel<TA, CW>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_patch_kernel<TA, CW>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
@@ -270,8 +264,7 @@ hipError_t launch_wgrad_patch(const WgradArgs& a0, hipStream_t st) {
   // Pixel-tile split: every workgroup ends with a TAx288 LDS-reduce + global-atomic epilogue worth about E
   // tiles of work, and workgroups run in rounds of `slots` (1 resident per CU for TA=64, 2 otherwise).
   // Pick the split that minimises rounds * (tiles_per_workgroup + E).
-  static int cus = 0;
-  if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+  const int cus = device_cu_count();
   const int pairs = nchunk * tilesA;
   const int slots = cus * (TA == 64 ? 1 : 2);
   const double E = TA == 64 ? 2.0 : (TA == 32 ? 1.0 : 0.5);

@@ -242,15 +242,9 @@ static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nbl
   size_t lds = (size_t)(2 * 64 * TA + 2 * kPP * kCW) * sizeof(float);
   const size_t rl = (size_t)9 * TA * kCW * sizeof(float);
   if (lds < rl) lds = rl;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_wino_kernel<TA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  if (prof_on()) prof_begin(cls, a.flops, st);
-  hipLaunchKernelGGL((wgrad_wino_kernel<TA>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
-  if (prof_on()) prof_end(st);
+  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_wino_kernel<TA>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_wino_kernel<TA>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -268,8 +262,7 @@ hipError_t launch_wgrad_wino(const WgradArgs& a0, hipStream_t st) {
   const int nchunk = a.Ctot / kCW, tilesA = a.Cout / TA;
   const int nstages = a.N * (a.Ho / kSH) * (a.Wo / kSW);
   // same cost model as wgrad_patch: rounds x (stages per workgroup + epilogue worth E stages)
-  static int cus = 0;
-  if (!cus) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+  const int cus = device_cu_count();
   const int pairs = nchunk * tilesA;
   const int slots = cus * 2;
   const double E = TA == 64 ? 4.0 : (TA == 32 ? 2.0 : 1.0);

@@ -58,10 +58,11 @@ class _DiceBCEFunction(torch.autograd.Function):
         need_grad = logits.requires_grad
         cp = 4
         dl = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device) if need_grad else None
-        L.check(L.lib().uwm_loss(C.c_void_p(xp), ld, C.c_void_p(tp), tdt, npix, float(w_dice), float(w_bce),
-                                 float(smooth), float(eps), C.c_void_p(scratch.data_ptr()),
-                                 C.c_void_p(out.data_ptr()), C.c_void_p(dl.data_ptr() if need_grad else 0), cp, 1.0,
-                                 C.c_void_p(L.stream_ptr(x.device))))
+        with L.on_device(x):
+            L.check(L.lib().uwm_loss(C.c_void_p(xp), ld, C.c_void_p(tp), tdt, npix, float(w_dice), float(w_bce),
+                                     float(smooth), float(eps), C.c_void_p(scratch.data_ptr()),
+                                     C.c_void_p(out.data_ptr()), C.c_void_p(dl.data_ptr() if need_grad else 0), cp, 1.0,
+                                     C.c_void_p(L.stream_ptr(x.device))))
         ctx.dl = dl
         ctx.in_shape = tuple(logits.shape)
         return out[0].clone()

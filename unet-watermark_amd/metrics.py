@@ -24,8 +24,9 @@ def get_stats(output: torch.Tensor, target: torch.Tensor, threshold: float = 0.5
     n, h, w = x.shape
     t, tp_, tdt = _target_plane(target, n, h * w)
     out = torch.empty((n, 4), dtype=torch.int64, device=x.device)
-    L.check(L.lib().uwm_stats(C.c_void_p(xp), ld, C.c_void_p(tp_), tdt, n, h * w, float(threshold),
-                              int(apply_sigmoid), C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr(x.device))))
+    with L.on_device(x):
+        L.check(L.lib().uwm_stats(C.c_void_p(xp), ld, C.c_void_p(tp_), tdt, n, h * w, float(threshold),
+                                  int(apply_sigmoid), C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr(x.device))))
     return out[:, 0:1], out[:, 1:2], out[:, 2:3], out[:, 3:4]
 
 
@@ -53,6 +54,28 @@ def logits_metrics(logits, target, threshold: float = 0.5):
     return micro_scores(*get_stats(logits, target, threshold, True))
 
 
+def _soft_sums(pred: torch.Tensor, target: torch.Tensor):
+    """Σ pred·target, Σ pred, Σ target over every element, accumulated in fp64 (one D2H for the three)."""
+    p = pred.reshape(-1)
+    t = target.reshape(-1).to(p.dtype if p.dtype.is_floating_point else torch.float32)
+    p = p.to(t.dtype)
+    s = torch.stack([(p * t).sum(dtype=torch.float64), p.sum(dtype=torch.float64), t.sum(dtype=torch.float64)])
+    return [float(v) for v in s.cpu()]
+
+
+def dice_coef(pred, target, smooth: float = 1e-5) -> float:
+    """Soft Dice coefficient (2·Σpt + s) / (Σp + Σt + s) over the flattened tensors —
+    /root/reference/src/utils/metrics.py:39-45.  `pred` = probabilities (or a hard mask), any device."""
+    i, sp, st = _soft_sums(pred, target)
+    return (2.0 * i + smooth) / (sp + st + smooth)
+
+
+def iou_score(pred, target, smooth: float = 1e-5) -> float:
+    """Soft IoU (Σpt + s) / (Σp + Σt − Σpt + s) — /root/reference/src/utils/metrics.py:47-54."""
+    i, sp, st = _soft_sums(pred, target)
+    return (i + smooth) / (sp + st - i + smooth)
+
+
 def threshold_mask(logits: torch.Tensor, threshold: float = 0.5, apply_sigmoid: bool = False) -> torch.Tensor:
     """(N,1,H,W)|(N,H,W) logits -> uint8 {0,255} (N,H,W).  Default reproduces the reference's quirk of
     thresholding RAW logits (src/predict.py:624); apply_sigmoid=True is watermark_filter.py's form."""
@@ -61,8 +84,9 @@ def threshold_mask(logits: torch.Tensor, threshold: float = 0.5, apply_sigmoid: 
     x, xp, ld = _logit_plane(logits.detach())
     n, h, w = x.shape
     out = torch.empty((n, h, w), dtype=torch.uint8, device=x.device)
-    L.check(L.lib().uwm_threshold(C.c_void_p(xp), ld, n * h * w, float(threshold), int(apply_sigmoid),
-                                  C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr(x.device))))
+    with L.on_device(x):
+        L.check(L.lib().uwm_threshold(C.c_void_p(xp), ld, n * h * w, float(threshold), int(apply_sigmoid),
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(L.stream_ptr(x.device))))
     return out
 
 
@@ -76,7 +100,8 @@ def resize_threshold(logits: torch.Tensor, size, threshold: float = 0.5, apply_s
     H, W = int(size[0]), int(size[1])
     out = torch.empty((n, H, W), dtype=torch.uint8, device=x.device)
     rs = torch.empty((n, H, W), dtype=torch.float32, device=x.device) if return_resized else None
-    L.check(L.lib().uwm_resize_threshold(C.c_void_p(xp), ld, n, h, w, H, W, float(threshold), int(apply_sigmoid),
-                                         C.c_void_p(out.data_ptr()), C.c_void_p(rs.data_ptr() if rs is not None else 0),
-                                         C.c_void_p(L.stream_ptr(x.device))))
+    with L.on_device(x):
+        L.check(L.lib().uwm_resize_threshold(C.c_void_p(xp), ld, n, h, w, H, W, float(threshold), int(apply_sigmoid),
+                                             C.c_void_p(out.data_ptr()), C.c_void_p(rs.data_ptr() if rs is not None else 0),
+                                             C.c_void_p(L.stream_ptr(x.device))))
     return (out, rs) if return_resized else out

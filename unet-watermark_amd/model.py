@@ -54,6 +54,8 @@ class _UnetFunction(torch.autograd.Function):
                                "(one forward/backward pair at a time per model)")
         dl = m._as_padded_dlogits(grad_out)
         m._backward_raw(dl)
+        if m._arena_grads_only:         # a fused flat optimizer consumes the arena itself (train.py): no per-parameter copies
+            return (None, None) + (None,) * len(m._plist)
         grads = tuple(m._grad_views[i] if p.requires_grad else None for i, p in enumerate(m._plist))
         return (None, None) + grads
 
@@ -145,6 +147,7 @@ class Unet(nn.Module):
         self._n_mb = lib.uwm_num_mbconv_blocks(h)
         self._mb_drop = [float(lib.uwm_mbconv_drop_rate(h, i)) for i in range(self._n_mb)]
         self.drop_connect = self._n_mb > 0
+        self._arena_grads_only = False    # set by the fused flat optimizers: backward() leaves p.grad unset, gradients stay in the arena
         self._keep_override = None        # tests: {0,1} keep masks [n_blocks, N] instead of a random draw
         self._rowscale = None
         self.reset_parameters()
@@ -215,6 +218,12 @@ class Unet(nn.Module):
 
     def num_parameters(self) -> int:
         return int(L.lib().uwm_param_count(self._h))
+
+    def conv_flops(self, h: int, w: int):
+        """Algorithmic conv FLOPs per image at h x w: (forward, forward+backward) — SURVEY.md 8(d)."""
+        f, fb = C.c_double(), C.c_double()
+        L.check(L.lib().uwm_conv_flops(self._h, int(h), int(w), C.byref(f), C.byref(fb)))
+        return f.value, fb.value
 
     # ------------------------------------------------------------------ raw entry points
     def _require_gpu(self, x: Optional[torch.Tensor] = None):

@@ -75,61 +75,188 @@ def broadcast_model(model, src: int = 0, group=None):
     dist.broadcast(model._buffer_arena, src=src, group=group)
 
 
-class FusedAdam(torch.optim.Optimizer):
-    """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (coupled L2) as ONE kernel launch
-    over the model's flat parameter arena (/root/reference/src/train.py:266-270 builds optim.Adam)."""
+class _FusedFlatOptimizer(torch.optim.Optimizer):
+    """Base of the fused optimizers: ONE kernel launch over the model's flat parameter arena, reading the flat
+    GRADIENT arena the last backward wrote.
 
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None):
+    What that implies (and differs from a per-parameter torch optimizer):
+    * the gradient arena is overwritten, not accumulated, by every backward, and `p.grad` is never read: gradient
+      accumulation over several backward() calls is not available on this path (use torch.optim.* on
+      model.parameters() with the autograd path for that);
+    * every parameter is updated: a frozen parameter (requires_grad=False) raises instead of being silently trained;
+    * by default the autograd path stops materialising `p.grad` (a copy of the whole arena per step that nothing on this
+      path reads); pass materialize_grads=True to keep `p.grad` populated.
+    Checkpoints: state_dict() / load_state_dict() use torch.optim's own layout ({'state': {i: {...}}, 'param_groups'}),
+    per parameter and in logical (OIHW) shape, so a reference periodic checkpoint (/root/reference/src/train.py:441-458)
+    resumes here and ours resumes there; a layout it does not recognise is skipped with a warning (weights only)."""
+
+    _SLOTS = ()          # names of the per-parameter state tensors, in arena order
+
+    def __init__(self, model, defaults, max_grad_norm=None, materialize_grads=False):
         self.model = model
-        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        super().__init__(list(model.parameters()), defaults)
         self.max_grad_norm = max_grad_norm           # TRAIN.GRADIENT_CLIP (config.py:54; unused by the reference's train.py)
         self._clip_scratch = None
-        self._m = None
-        self._v = None
+        self._bufs = None
         self._step = 0
+        self._checked_flags = None
+        model._arena_grads_only = not materialize_grads
 
     def _state_init(self):
         p = self.model.flat_parameters()
-        if self._m is None or self._m.device != p.device:
-            self._m = torch.zeros_like(p)
-            self._v = torch.zeros_like(p)
+        if self._bufs is None or self._bufs[0].device != p.device:
+            old = self._bufs
+            self._bufs = [torch.zeros_like(p) for _ in self._SLOTS]
+            if old is not None:
+                for n, o in zip(self._bufs, old):
+                    n.copy_(o)
 
-    @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
-        loss = closure() if closure is not None else None
-        g = self.param_groups[0]
-        self._state_init()
-        self._step += 1
-        p = self.model.flat_parameters()
-        gr = self.model.flat_grads()
-        args = (C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._m.data_ptr()),
-                C.c_void_p(self._v.data_ptr()), p.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                float(g["eps"]), float(g["weight_decay"]), self._step, float(grad_scale))
-        if self.max_grad_norm:
-            if self._clip_scratch is None or self._clip_scratch.device != p.device:
-                self._clip_scratch = torch.zeros(2, dtype=torch.float64, device=p.device)
-            L.check(L.lib().uwm_adam_clip(*args, float(self.max_grad_norm), C.c_void_p(self._clip_scratch.data_ptr()),
-                                          C.c_void_p(L.stream_ptr(p.device))))
-        else:
-            L.check(L.lib().uwm_adam(*args, C.c_void_p(L.stream_ptr(p.device))))
-        return loss
+    def _check_frozen(self):
+        flags = tuple(p.requires_grad for p in self.model.parameters())
+        if flags != self._checked_flags:
+            if not all(flags):
+                names = [n for n, p in self.model.named_parameters() if not p.requires_grad]
+                raise NotImplementedError(
+                    f"{type(self).__name__} updates the whole flat arena and cannot skip frozen parameters "
+                    f"({len(names)} have requires_grad=False, e.g. {names[0]}); use torch.optim on model.parameters()")
+            self._checked_flags = flags
+
+    def _clip_ptr(self, p):
+        if not self.max_grad_norm:
+            return None
+        if self._clip_scratch is None or self._clip_scratch.device != p.device:
+            self._clip_scratch = torch.zeros(2, dtype=torch.float64, device=p.device)
+        return C.c_void_p(self._clip_scratch.data_ptr())
 
     def zero_grad(self, set_to_none: bool = True):
         # gradients live in the flat arena and are overwritten (not accumulated) by every backward
         for p in self.model.parameters():
             p.grad = None
 
+    # ---- torch.optim-compatible state
+    def _views(self, flat):
+        return [flat.as_strided(shape, stride, off) for off, shape, stride in self.model._pinfo]
+
     def state_dict(self):
-        return {"step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        self._state_init()
+        n = len(self.model._pinfo)
+        per = [self._views(b) for b in self._bufs]
+        state = {}
+        if self._step > 0:
+            for i in range(n):
+                ent = {"step": torch.tensor(float(self._step))}
+                for name, views in zip(self._SLOTS, per):
+                    ent[name] = views[i].detach().clone().contiguous()
+                state[i] = ent
+        groups = [dict({k: v for k, v in g.items() if k != "params"}, params=list(range(n))) for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._step = int(sd["step"])
+        import warnings
         self._state_init()
-        if sd.get("exp_avg") is not None:
-            self._m.copy_(sd["exp_avg"]); self._v.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update(s)
+        if "state" in sd and "param_groups" in sd:                      # torch.optim layout (ours and the reference's)
+            st = sd["state"]
+            n = len(self.model._pinfo)
+            per = [self._views(b) for b in self._bufs]
+            if len(st) not in (0, n) or any(nm not in ent for ent in st.values() for nm in self._SLOTS):
+                warnings.warn(f"{type(self).__name__}: optimizer state has {len(st)} entries / other slots than "
+                              f"{self._SLOTS} for {n} parameters; optimizer state NOT restored (weights only)")
+                return
+            for b in self._bufs:
+                b.zero_()
+            step = 0
+            for i, ent in st.items():
+                i = int(i)
+                for name, views in zip(self._SLOTS, per):
+                    t = ent[name]
+                    if tuple(t.shape) != tuple(views[i].shape):
+                        warnings.warn(f"{type(self).__name__}: state {name}[{i}] has shape {tuple(t.shape)}, expected "
+                                      f"{tuple(views[i].shape)}; optimizer state NOT restored (weights only)")
+                        for b in self._bufs:
+                            b.zero_()
+                        self._step = 0
+                        return
+                    views[i].copy_(t.to(views[i].device))
+                step = max(step, int(float(ent.get("step", 0))))
+            self._step = step
+        elif "step" in sd and all(nm in sd for nm in self._SLOTS):      # round-1 flat-arena layout
+            self._step = int(sd["step"])
+            for b, nm in zip(self._bufs, self._SLOTS):
+                if sd[nm] is not None and sd[nm].numel() == b.numel():
+                    b.copy_(sd[nm].to(b.device))
+        else:
+            warnings.warn(f"{type(self).__name__}: unrecognised optimizer state layout (keys {sorted(sd)[:6]}); "
+                          f"optimizer state NOT restored (weights only)")
+            return
+        for g, s_ in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in s_.items() if k != "params"})
+
+
+class FusedAdam(_FusedFlatOptimizer):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (coupled L2) as ONE kernel launch
+    over the model's flat parameter arena (/root/reference/src/train.py:266-270 builds optim.Adam)."""
+
+    _SLOTS = ("exp_avg", "exp_avg_sq")
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None,
+                 materialize_grads=False):
+        super().__init__(model, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay), max_grad_norm,
+                         materialize_grads)
+
+    @property
+    def _m(self):
+        return self._bufs[0] if self._bufs else None
+
+    @property
+    def _v(self):
+        return self._bufs[1] if self._bufs else None
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self._state_init()
+        self._check_frozen()
+        self._step += 1
+        p = self.model.flat_parameters()
+        gr = self.model.flat_grads()
+        args = (C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._bufs[0].data_ptr()),
+                C.c_void_p(self._bufs[1].data_ptr()), p.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                float(g["eps"]), float(g["weight_decay"]), self._step, float(grad_scale))
+        with L.on_device(p):
+            if self.max_grad_norm:
+                L.check(L.lib().uwm_adam_clip(*args, float(self.max_grad_norm), self._clip_ptr(p),
+                                              C.c_void_p(L.stream_ptr(p.device))))
+            else:
+                L.check(L.lib().uwm_adam(*args, C.c_void_p(L.stream_ptr(p.device))))
+        return loss
+
+
+class FusedSGD(_FusedFlatOptimizer):
+    """torch.optim.SGD(lr, momentum=0.9, weight_decay) — the reference's OPTIMIZER.NAME == "SGD" branch
+    (/root/reference/src/train.py:272-278) — as one launch over the flat arena (uwm_sgd)."""
+
+    _SLOTS = ("momentum_buffer",)
+
+    def __init__(self, model, lr=1e-4, momentum=0.9, weight_decay=0.0, max_grad_norm=None, materialize_grads=False):
+        super().__init__(model, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=0.0, nesterov=False),
+                         max_grad_norm, materialize_grads)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self._state_init()
+        self._check_frozen()
+        self._step += 1
+        p = self.model.flat_parameters()
+        gr = self.model.flat_grads()
+        with L.on_device(p):
+            L.check(L.lib().uwm_sgd(C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._bufs[0].data_ptr()),
+                                    p.numel(), float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), self._step,
+                                    float(grad_scale), float(self.max_grad_norm or 0.0), self._clip_ptr(p),
+                                    C.c_void_p(L.stream_ptr(p.device))))
+        return loss
 
 
 class Trainer:
@@ -138,10 +265,16 @@ class Trainer:
 
     def __init__(self, model, w_dice: float = 1.0, w_bce: float = 0.0, smooth: float = 1e-5, eps: float = 1e-7,
                  lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0,
-                 group=None, overlap_comm: bool = True, force_ddp: bool = False, max_grad_norm=None):
+                 group=None, overlap_comm: bool = True, force_ddp: bool = False, max_grad_norm=None,
+                 optimizer: str = "Adam", momentum: float = 0.9):
         self.model = model
         self.w_dice, self.w_bce, self.smooth, self.eps = float(w_dice), float(w_bce), float(smooth), float(eps)
-        self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        if optimizer == "Adam":          # cfg.OPTIMIZER.NAME (/root/reference/src/train.py:266-279)
+            self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        elif optimizer == "SGD":
+            self.opt = FusedSGD(model, lr=lr, momentum=momentum, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        else:
+            raise ValueError(f"unsupported optimizer: {optimizer!r} (Adam | SGD)")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.overlap = overlap_comm
