@@ -438,12 +438,16 @@ hipError_t launch_bn_bwd_act(const float* g, const float* y, const float* mean, 
 }
 
 // ---------------------------------------------------------------- squeeze-and-excitation
-// out[n][c] += scale * sum over hw of v,  v = a * b (b given: the SE backward's sum g*a1), v = a (plain pooling), or
+// out[n][c] = scale * sum over hw of v,  v = a * b (b given: the SE backward's sum g*a1), v = a (plain pooling), or
 // v = swish(a*sc + sh) which is ALSO written to act_out (the forward: the activation pass and the squeeze pooling are one
-// pass over the tensor).  out zeroed by the caller.
+// pass over the tensor).  Two stages, no atomics: workgroup (bx, n, cz) stores ONE partial per channel into
+// part[bx][n][c]; se_reduce_finish adds the partials of a (n, c) in block order.  The split of hw over workgroups depends
+// on hw and C only — never on N — so the result is bit-identical from run to run AND across batch sizes (the eval forward
+// of an image does not depend on its batch mates: BASELINE config 5's "equal to the batch-1 path" property).
+constexpr int kSeMaxParts = 64;
 __global__ __launch_bounds__(256) void se_reduce_hw_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ sc,
                                                            const float* __restrict__ sh, float* __restrict__ act_out, size_t hw, int C, int CW,
-                                                           float scale, float* __restrict__ out) {
+                                                           float* __restrict__ part) {
   __shared__ float red[256 * 4];
   const int n = blockIdx.y;
   const int c0 = blockIdx.z * CW;
@@ -478,27 +482,42 @@ __global__ __launch_bounds__(256) void se_reduce_hw_kernel(const float* __restri
     const int q = t / 4, e = t % 4;
     float sum = 0.f;
     for (int k = 0; k < tr; ++k) sum += red[(k * tc + q) * 4 + e];
-    atomicAdd(out + (size_t)n * C + c0 + q * 4 + e, sum * scale);
+    part[((size_t)blockIdx.x * gridDim.y + n) * C + c0 + q * 4 + e] = sum;
   }
 }
-static hipError_t se_reduce_launch(const float* a, const float* b, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C,
-                                   float scale, float* out, hipStream_t st) {
+__global__ __launch_bounds__(256) void se_reduce_finish_kernel(const float* __restrict__ part, int nparts, size_t nc, float scale, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nc) return;
+  float s = 0.f;
+  for (int k = 0; k < nparts; ++k) s += part[(size_t)k * nc + i];
+  out[i] = s * scale;
+}
+static int se_parts(size_t hw, int C) {
   const int CW = pick_cw(C);
-  if (!CW) return hipErrorInvalidValue;
+  if (!CW) return 0;
   const int tr = 256 / (CW / 4);
-  unsigned bx = (unsigned)((hw + (size_t)tr * 16 - 1) / ((size_t)tr * 16));
-  const unsigned cap = std::max(1u, 2048u / (unsigned)(N * (C / CW)));
-  if (bx > cap) bx = cap; if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(se_reduce_hw_kernel, dim3(bx, N, C / CW), dim3(256), 0, st, a, b, sc, sh, act_out, hw, C, CW, scale, out);
+  size_t bx = (hw + (size_t)tr * 16 - 1) / ((size_t)tr * 16);
+  if (bx > (size_t)kSeMaxParts) bx = kSeMaxParts;
+  return bx < 1 ? 1 : (int)bx;
+}
+size_t se_reduce_scratch_floats(int N, int C) { return (size_t)kSeMaxParts * N * C; }
+static hipError_t se_reduce_launch(const float* a, const float* b, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C,
+                                   float scale, float* out, float* part, hipStream_t st) {
+  const int CW = pick_cw(C);
+  if (!CW || !part) return hipErrorInvalidValue;
+  const int bx = se_parts(hw, C);
+  hipLaunchKernelGGL(se_reduce_hw_kernel, dim3(bx, N, C / CW), dim3(256), 0, st, a, b, sc, sh, act_out, hw, C, CW, part);
+  const size_t nc = (size_t)N * C;
+  hipLaunchKernelGGL(se_reduce_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, part, bx, nc, scale, out);
   return hipGetLastError();
 }
-hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, hipStream_t st) {
-  return se_reduce_launch(a, b, nullptr, nullptr, nullptr, N, hw, C, scale, out, st);
+hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, float* part, hipStream_t st) {
+  return se_reduce_launch(a, b, nullptr, nullptr, nullptr, N, hw, C, scale, out, part, st);
 }
-// act_out = swish(y*sc + sh) and pool[n][c] += mean over hw of it, in one pass
+// act_out = swish(y*sc + sh) and pool[n][c] = mean over hw of it, in one pass (+ the tiny finish launch)
 hipError_t launch_swish_pool(const float* y, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C, float* pool,
-                             hipStream_t st) {
-  return se_reduce_launch(y, nullptr, sc, sh, act_out, N, hw, C, (float)(1.0 / (double)hw), pool, st);
+                             float* part, hipStream_t st) {
+  return se_reduce_launch(y, nullptr, sc, sh, act_out, N, hw, C, (float)(1.0 / (double)hw), pool, part, st);
 }
 // SE FCs, forward, two small launches.  (1) grid (N, ceil(nsq/4)): a wave per hidden unit, lanes along the C inputs
 // (coalesced row of W1 [nsq][K1pad]), shuffle reduce: hpre = W1 pool + b1 (kept for the backward), hid = swish(hpre).

@@ -208,10 +208,11 @@ hipError_t launch_bn_bwd_act(const float* g, const float* y, const float* mean, 
                              const float* shift, const float* se_s, const float* gpool, int N, size_t hw, double* dgamma, double* dbeta,
                              float* dy, float* gamma_grad, float* beta_grad, int C, hipStream_t st);
 hipError_t launch_colstats(const float* y, size_t npix, int C, double* ssum, double* ssq, hipStream_t st);
-// out[n][c] += scale * sum_hw a[n][hw][c] (* b[n][hw][c]); out zeroed by the caller
-hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, hipStream_t st);
+// out[n][c] = scale * sum_hw a[n][hw][c] (* b[n][hw][c]); deterministic two-stage sum, part: se_reduce_scratch_floats(N, C) floats
+size_t se_reduce_scratch_floats(int N, int C);
+hipError_t launch_se_reduce_hw(const float* a, const float* b, int N, size_t hw, int C, float scale, float* out, float* part, hipStream_t st);
 hipError_t launch_swish_pool(const float* y, const float* sc, const float* sh, float* act_out, int N, size_t hw, int C, float* pool,
-                             hipStream_t st);
+                             float* part, hipStream_t st);
 hipError_t launch_se_fc_fwd(const float* pool, const float* w1, const float* b1, int K1pad, const float* w2, const float* b2,
                             int K2pad, int N, int C, int nsq, float* hpre, float* hid /* scratch [N][nsq] */, float* s, hipStream_t st);
 // gs [N][C] is overwritten (gz2); acc1: scratch [N][nsq] zeroed by the caller; parameter gradients are plain stores

@@ -76,6 +76,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   std::vector<int> mh, mw;          // EfficientNet per block: output height / width
   size_t dw_part = 0;               // EfficientNet: partial sums of the two-stage depthwise weight gradient (largest layer)
   size_t se_g = 0;                  // EfficientNet: SE backward gpool scratch [N][max mid]
+  size_t se_part = 0;               // EfficientNet: partial sums of the two-stage (deterministic) SE pooling, largest layer
   std::vector<size_t> se_pool, se_gs;   // per block: pooled mean [N][mid] (forward) / {gs [N][mid], acc1 [N][nsq]} (backward), each set contiguous:
   size_t se_pool_all = 0, se_pool_floats = 0, se_gs_all = 0, se_gs_floats = 0;   // ONE memset per forward / backward instead of one per block
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
@@ -371,6 +372,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
     p.se_pool.assign(nb, 0); p.se_gs.assign(nb, 0);
     for (size_t i = 0; i < nb; ++i) { p.se_pool[i] = p.se_pool_floats; p.se_pool_floats += (size_t)rup((long long)N * m->mb[i].mid, 64); }
     p.se_pool_all = alloc(p.se_pool_floats);
+    { size_t mm = 0; for (auto& b : m->mb) mm = std::max(mm, (size_t)b.mid); p.se_part = alloc(se_reduce_scratch_floats(N, (int)mm)); }
     for (size_t i = 0; i < nb; ++i) p.se_pool[i] += p.se_pool_all;
     for (; bi < nb; ++bi) {
       const MBL& b = m->mb[bi];
@@ -686,7 +688,6 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     LCHK(launch_swish_fwd(c.F(p.y[m->stem]), sc, sf, m->f1C, c.F(p.stem_a), (size_t)N * h * w, st));
     f1 = mk_src(c.F(p.stem_a), m->f1C, h, w);
     m->keep_fwd = training ? m->keep : nullptr;
-    HIPCHK(hipMemsetAsync(c.F(p.se_pool_all), 0, p.se_pool_floats * sizeof(float), st));
     Src cur = f1;
     for (size_t bi = 0; bi < m->mb.size(); ++bi) {
       const MBL& b = m->mb[bi];
@@ -708,8 +709,8 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
         LCHK(run_bn_finalize(c, dw.bn, npo, 1));
       }
       bn_ss(b.cdw, &sc, &sf);
-      float* pool = c.F(p.se_pool[bi]); float* sv = c.F(p.se[bi]); float* hpre = sv + (size_t)N * b.mid;      // (pools zeroed by one memset above)
-      LCHK(launch_swish_pool(c.F(p.y[b.cdw]), sc, sf, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, pool, st));
+      float* pool = c.F(p.se_pool[bi]); float* sv = c.F(p.se[bi]); float* hpre = sv + (size_t)N * b.mid;
+      LCHK(launch_swish_pool(c.F(p.y[b.cdw]), sc, sf, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, pool, c.F(p.se_part), st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_fwd(pool, m->params + cr.w_off, m->params + cr.bias_off, cr.Kpad, m->params + cx.w_off,
                             m->params + cx.bias_off, cx.Kpad, N, b.mid, b.nsq, hpre, hpre + (size_t)N * rup(b.nsq, 4), sv, st));
@@ -932,7 +933,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       // squeeze-and-excitation: gs = sum_hw g*a1 ; FC backward ; g_a1 = g*s + gpool/hw, then through swish(bn1(.))
       float* pool = c.F(p.se_pool[bi]); float* sv = c.F(p.se[bi]); float* hpre = sv + (size_t)N * b.mid;
       float* gs = c.F(p.se_gs[bi]); float* acc1 = gs + (size_t)N * b.mid; float* gpool = c.F(p.se_g);      // gs / acc1 zeroed at the start of the backward
-      LCHK(launch_se_reduce_hw(gM, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, 1.f, gs, st));
+      LCHK(launch_se_reduce_hw(gM, c.F(p.a1[bi]), N, (size_t)ho * wo, b.mid, 1.f, gs, c.F(p.se_part), st));
       const ConvL& cr = m->convs[b.cr]; const ConvL& cx = m->convs[b.cx];
       LCHK(launch_se_fc_bwd(gs, sv, hpre, pool, m->params + cr.w_off, cr.Kpad, m->params + cx.w_off, cx.Kpad, N, b.mid, b.nsq,
                             gpool, acc1, m->grads + cr.w_off, m->grads + cr.bias_off, m->grads + cx.w_off, m->grads + cx.bias_off, st));
