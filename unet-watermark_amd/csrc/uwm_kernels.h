@@ -82,6 +82,8 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   int N, Ho, Wo, Cout, M;
   int Hl, Wl, stride, pad;
   int nsplit, msplit;        // pixel range per split (multiple of 32)
+  float* part;               // scratch for per-split partial dW tiles (Winograd wgrad: deterministic two-stage sum) or nullptr
+  size_t part_floats;        // its capacity
   int force_igemm;           // tests: 1 = never route to wgrad_patch
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
@@ -120,6 +122,7 @@ bool wgrad_patch_applicable(const WgradArgs& a);
 hipError_t launch_wgrad_patch(const WgradArgs& a, hipStream_t st);
 bool wgrad_wino_applicable(const WgradArgs& a);            // Winograd-domain wgrad (wgrad_wino.hip)
 hipError_t launch_wgrad_wino(const WgradArgs& a, hipStream_t st);
+size_t wgrad_wino_scratch_floats();                         // workspace the model plans for WgradArgs::part
 bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);

@@ -82,6 +82,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
+  size_t wg_part = 0;               // per-split partial sums of the Winograd weight gradient (deterministic two-stage reduce)
 };
 
 struct uwm_model {
@@ -409,6 +410,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   }
   p.oh[m->head] = H; p.ow[m->head] = W;
   if (training) {
+    p.wg_part = alloc(wgrad_wino_scratch_floats());
     // gradient buffers (same shapes as their activations)
     h = H / 2; w = W / 2;
     p.g[m->stem] = alloc((size_t)N * h * w * stemC);
@@ -540,6 +542,7 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
                    (double)cv.Cout * cv.Kpad);
   a.wino = c.m->plan.wino_mode + 1;
+  a.part = c.F(c.m->plan.wg_part); a.part_floats = wgrad_wino_scratch_floats();
   if (c.wst && c.wst != c.st) {
     // fork: the side stream must see everything enqueued so far on the main stream (dy, activations)
     hipError_t e = hipEventRecord(c.m->ev_fork, c.st);

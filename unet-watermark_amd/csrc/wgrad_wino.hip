@@ -14,8 +14,17 @@
 // (A dY A^T)[i][0..3] values of ITS (tile, co) and the (B^T d B)[i][0..3] values of ITS (tile, c) in
 // registers from 4-byte LDS reads — MFMA k index = tile — and feeds 4 xi x (TA/16) x 2 MFMAs per 4 tiles.
 // Epilogue: per-wave column transform (Z G), cross-wave row transform (G^T .) through LDS in three
-// ordered phases (plain read-add-write, no LDS atomics), then coalesced fp32 global atomics.
+// ordered phases (plain read-add-write, no LDS atomics), then coalesced stores.
+//
+// Round 2: TA = 64 | 32 run on wgrad_wino2_kernel below (a wave owns output-channel blocks x one input-channel block at
+// ALL 16 Winograd points: 25 % fewer LDS operand reads per MFMA, the whole G^T Z G epilogue in registers, stage-boundary
+// loads folded into the MFMA blocks); the row-per-wave kernel above it stays for TA = 16.  Neither uses global atomics
+// any more: a workgroup stores ONE partial dW tile per pixel split and wgrad_reduce_kernel adds the splits in order —
+// the weight gradient is bit-reproducible from run to run (float atomics were not), and the write traffic is the same
+// bytes as plain stores instead of 4-byte atomic requests.  Blocks of one pixel split are dealt to ONE XCD, so the dY /
+// input range they all stream is fetched from HBM once per XCD L2 instead of once per block.
 #include "uwm_kernels.h"
+#include <cstdlib>
 
 namespace uwm {
 
@@ -229,55 +238,377 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WgradArgs a) {
   if (wave == 1) upd(2, 0.5f, false);
   if (wave == 2) upd(0, 0.5f, false);
   __syncthreads();
+  // one partial tile per pixel split (plain stores; wgrad_reduce_kernel adds the splits in order), or straight into dW
+  float* const dst = a.nsplit > 1 ? a.part + (size_t)split * a.wrows * a.Kpad : a.dw;
   for (int i = tid; i < 9 * RS; i += 256) {
     const int t = i / RS, rem = i - t * RS;
     const int co = rem / kCW, cch = rem - co * kCW;
     const int row = a0 + co;
-    if (row < a.wrows) atomicAdd(a.dw + (size_t)row * a.Kpad + t * a.Ctot + cc * kCW + cch, R[i]);
+    if (row < a.wrows) {
+      float* q = dst + (size_t)row * a.Kpad + t * a.Ctot + cc * kCW + cch;
+      *q = a.nsplit > 1 ? R[i] : *q + R[i];
+    }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad_wino2: TA = 64 | 32.  Same workgroup tile (TA output x 32 input channels), same 4x16-pixel stages, same LDS
+// images and loaders as above; what changes is who multiplies what:
+//   wave w owns output-channel blocks ca in [(w>>1)*NCA, +NCA) (NCA = TA/32) x input-channel block cb = w&1 at ALL 16
+//   Winograd points.  Per 4 tiles it reads its raw dY (4 pixels per ca) and its raw 4x4 input patch (16 values) once,
+//   forms the full A dY A^T and B^T d B in registers and issues 16*NCA MFMAs: 8 + 16 = 24 LDS reads per 32 MFMAs
+//   instead of 32, and nothing a lane reads is read again by another wave's lane for the same product.
+//   The accumulators of a lane are Z[xi] of ITS (co, ci) elements for every xi, so dW = G^T Z G needs no cross-wave
+//   exchange: no LDS epilogue, no extra barriers.
+//   The next stage's dY DMA and patch loads are issued inside MFMA block 0 / 1, the patch is written to LDS inside
+//   block 3: the stage boundary is the barrier alone.
+template <int TA>
+__global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(const WgradArgs a) {
+  static_assert(TA == 64 || TA == 32, "wgrad_wino2: TA = 64 | 32");
+  constexpr int NCA = TA / 32;             // output-channel MFMA tiles per wave
+  constexpr int UPP = TA / 4;              // 16-byte units per dY pixel
+  constexpr int YI = UPP / 4;              // LDS-DMA instructions per wave per stage (TA=64: 4, TA=32: 2)
+  constexpr int kYs = 64 * TA;             // floats per dY buffer
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Ys = smem;                        // [2][64 px][TA]       (16-channel blocks swizzled by tile parity)
+  float* const Ps = smem + 2 * kYs;              // [2][108 px][32]      (same swizzle)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int wca = (wave >> 1) * NCA, wcb = wave & 1;
+
+  const int nchunk = a.Ctot / kCW;
+  const int tilesA = a.Cout / TA;
+  const int tilesW = a.Wo / kSW, tilesH = a.Ho / kSH;
+  const int nstages = a.N * tilesH * tilesW;
+  const int pairs = nchunk * tilesA;
+  // block -> (pair, split).  With nsplit % 8 == 0 every block of a pixel split lands on the same XCD (blocks b and b + 8
+  // share one): XCD x serves splits x, x + 8, ... one after the other, its `pairs` blocks of a split side by side.
+  int pair, split;
+  {
+    const int b = blockIdx.x;
+    if ((a.nsplit & 7) == 0) { const int x = b & 7, idx = b >> 3; split = (idx / pairs) * 8 + x; pair = idx % pairs; }
+    else { pair = b % pairs; split = b / pairs; }
+  }
+  const int cc = pair % nchunk, ta = pair / nchunk;
+  const int a0 = ta * TA;
+  const int t0 = split * a.msplit, t1 = min(nstages, t0 + a.msplit);
+
+  // ---- patch loader: thread = (pixel of the 6x18 halo patch, 4-channel unit), rounds of 256 threads.  Every address is a
+  // wave-uniform stage origin (scalar registers) + a per-thread offset fixed for the whole launch; only the zero-padding
+  // predicate depends on the stage (which image borders it touches), as 4 scalar bits against 4 static bits per round.
+  const int chu = tid & 7;
+  const bool first = cc * kCW < a.C0;              // block-uniform: C0 is a multiple of the 32-channel chunk
+  const float* sp = first ? a.s0.ptr : a.s1.ptr;
+  const float* ssc = first ? a.s0.scale : a.s1.scale;
+  const float* ssh = first ? a.s0.shift : a.s1.shift;
+  const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
+  const int sup = first ? a.s0.up : a.s1.up;
+  const int trelu = first ? a.s0.relu : a.s1.relu;
+  const int cl = (first ? cc * kCW : cc * kCW - a.C0) + chu * 4;
+  const bool thas = ssc != nullptr;
+  f4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
+  if (thas) { tsc = *(const f4*)(ssc + cl); tsh = *(const f4*)(ssh + cl); }
+  // offsets are taken from the pixel one row up / one column left of the stage origin (two when upsampled), so they are >= 0
+  unsigned poff[kPRounds]; int ppos[kPRounds]; unsigned pflags = 0;
+  unsigned pcenter;                                // a pixel that always exists: the stage's own first pixel
+  {
+    const int sh1 = sup ? 1 : 0;
+    pcenter = (unsigned)((((1 + sh1) >> sh1) * sW + ((1 + sh1) >> sh1)) * sC + cl);
+#pragma unroll
+    for (int rd = 0; rd < kPRounds; ++rd) {
+      const int u = rd * 256 + tid;
+      const bool act = u < kPUnits;
+      const int pp = act ? (u >> 3) : 0;
+      const int py = pp / kPW, px = pp - py * kPW;
+      ppos[rd] = act ? pp * kCW + ((chu ^ (((px >> 1) & 1) << 2)) << 2) : -1;
+      poff[rd] = (unsigned)((((py + sh1) >> sh1) * sW + ((px + sh1) >> sh1)) * sC + cl);
+      const unsigned fl = (py == 0 ? 1u : 0u) | (py == kSH + 1 ? 2u : 0u) | (px == 0 ? 4u : 0u) | (px == kSW + 1 ? 8u : 0u);
+      pflags |= fl << (4 * rd);
+    }
+  }
+  // ---- dY DMA: instruction (i, wave) covers 16-byte units [(i*4+wave)*64, +64) of the [64 px][UPP] image
+  unsigned yoff[YI];
+#pragma unroll
+  for (int i = 0; i < YI; ++i) {
+    const int L = (i * 4 + wave) * 64 + lane;
+    const int px = L / UPP, su = L - px * UPP;
+    const int cu = su ^ (((px >> 1) & 1) << 2);      // global unit stored at LDS unit su (UPP >= 8 for both TA)
+    yoff[i] = (unsigned)(((px >> 4) * a.Wo + (px & 15)) * a.Cout + cu * 4);
+  }
+
+  f4 acc[4][4][NCA];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < NCA; ++q) acc[i][j][q] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  f4 pv[kPRounds]; unsigned pinv = 0;
+  auto stage_geo = [&](int t, int& n, int& h0, int& w0) {
+    const int tw = t % tilesW; const int q = t / tilesW;
+    h0 = (q % tilesH) * kSH; n = q / tilesH; w0 = tw * kSW;
+  };
+  auto y_dma = [&](int t, int buf, int i) {
+    int n, h0, w0; stage_geo(t, n, h0, w0);
+    const float* g0 = a.dy + ((size_t)((size_t)n * a.Ho + h0) * a.Wo + w0) * a.Cout + a0;     // wave-uniform
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g0 + yoff[i]), (lds_void*)(uintptr_t)(Ys + buf * kYs + (i * 4 + wave) * 256), 16, 0, 0);
+  };
+  auto patch_load = [&](int t) {
+    int n, h0, w0; stage_geo(t, n, h0, w0);
+    const int sh1 = sup ? 1 : 0;
+    // origin one (upsampled: two) pixels up-left of the stage: may lie before the tensor for the first stage of an image;
+    // lanes whose pixel is outside the image are redirected to the stage's own first pixel before the load
+    const long long org = ((long long)((long long)n * sH + ((h0 - 1 - sh1) >> sh1)) * sW + ((w0 - 1 - sh1) >> sh1)) * sC;
+    const float* g0 = sp + org;
+    const unsigned smask = ((h0 == 0 ? 1u : 0u) | (h0 + kSH == a.Hl ? 2u : 0u) | (w0 == 0 ? 4u : 0u) | (w0 + kSW == a.Wl ? 8u : 0u)) * 0x1111u;
+    pinv = pflags & smask;
+#pragma unroll
+    for (int rd = 0; rd < kPRounds; ++rd) {
+      const bool inv = ((pinv >> (4 * rd)) & 0xFu) != 0;
+      pv[rd] = *(const f4*)(g0 + (inv ? pcenter : poff[rd]));
+    }
+  };
+  auto patch_store = [&](int buf) {
+    float* ps = Ps + buf * kPP * kCW;
+#pragma unroll
+    for (int rd = 0; rd < kPRounds; ++rd) {
+      f4 v = pv[rd];
+      if (thas) {
+        v = v * tsc + tsh;
+        if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      if ((pinv >> (4 * rd)) & 0xFu) v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (ppos[rd] >= 0) *(f4*)(ps + ppos[rd]) = v;
+    }
+  };
+
+  // ---- software-pipelined operand path.  Raw LDS values of the NEXT 4-tile block are read one MFMA group (16 MFMAs,
+  // >= 512 cycles) ahead of their first use, so no MFMA ever waits for an LDS read it has just issued (round 1's kernel
+  // read, waited and multiplied in place: the matrix pipe idled for the LDS latency ~6 times per block).
+  //   dB[16]: raw 4x4 input patch of (tile, ci) ; dA[q][4]: raw 2x2 dY of (tile, co_q) ; V / Vn: B^T d B of this / the next block
+  float dB[16], dA[NCA][4], V[4][4];
+  // tile = ks*4 + lq  =>  ty = ks >> 1, tx = (ks & 1)*4 + lq: everything but lq is a compile-time constant of the block, and
+  // the swizzle parity (tx & 1) = (lq & 1) is a lane constant, so every operand read is ONE lane base + an immediate offset
+  const int lsw = (lq & 1) << 4;
+  const int bch = (wcb * 16 + li) ^ lsw;                       // input channel slot of pixel columns 2tx, 2tx+1 (2tx+2, 2tx+3: ^16)
+  const int pbase0 = (2 * lq) * kCW + bch, pbase1 = (2 * lq) * kCW + (bch ^ 16);
+  const int ybase = (2 * lq) * TA + ((wca * 16 + li) ^ lsw);   // co block q sits 16 floats further, on either side of the swizzle
+  const int yq1 = (((wca + 1) * 16 + li) ^ lsw) - ((wca * 16 + li) ^ lsw);
+  auto read_B = [&](const float* ps, int ks) {
+    const int koff = ((2 * (ks >> 1)) * kPW + 8 * (ks & 1)) * kCW;      // compile-time per unrolled block
+    const float* p0 = ps + pbase0 + koff; const float* p1 = ps + pbase1 + koff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dB[r * 4 + 0] = p0[(r * kPW + 0) * kCW]; dB[r * 4 + 1] = p0[(r * kPW + 1) * kCW];
+      dB[r * 4 + 2] = p1[(r * kPW + 2) * kCW]; dB[r * 4 + 3] = p1[(r * kPW + 3) * kCW];
+    }
+  };
+  auto read_A = [&](const float* ys, int ks, int q) {
+    const int koff = ((2 * (ks >> 1)) * 16 + 8 * (ks & 1)) * TA;
+    const float* yb = ys + ybase + koff + (q ? yq1 : 0);
+    dA[q][0] = yb[0]; dA[q][1] = yb[TA]; dA[q][2] = yb[16 * TA]; dA[q][3] = yb[17 * TA];
+  };
+  auto transform_B = [&](float (&o)[4][4]) {         // o = B^T d B
+    float r_[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      r_[0][x] = dB[0 + x] - dB[8 + x]; r_[1][x] = dB[4 + x] + dB[8 + x]; r_[2][x] = dB[8 + x] - dB[4 + x]; r_[3][x] = dB[4 + x] - dB[12 + x];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[i][0] = r_[i][0] - r_[i][2]; o[i][1] = r_[i][1] + r_[i][2]; o[i][2] = r_[i][2] - r_[i][1]; o[i][3] = r_[i][1] - r_[i][3];
+    }
+  };
+  auto mfma_group = [&](int q) {                     // 16 MFMAs: (A dY A^T)[i][j] of co block q  x  V[i][j]
+    const float y00 = dA[q][0], y01 = dA[q][1], y10 = dA[q][2], y11 = dA[q][3];
+    const float ta_[4] = {y00, y00 + y10, y00 - y10, -y10};
+    const float tb_[4] = {y01, y01 + y11, y01 - y11, -y11};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float p0 = ta_[i], p1 = ta_[i] + tb_[i], p2 = ta_[i] - tb_[i], p3 = -tb_[i];
+      acc[i][0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(p0, V[i][0], acc[i][0][q], 0, 0, 0);
+      acc[i][1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1, V[i][1], acc[i][1][q], 0, 0, 0);
+      acc[i][2][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(p2, V[i][2], acc[i][2][q], 0, 0, 0);
+      acc[i][3][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(p3, V[i][3], acc[i][3][q], 0, 0, 0);
+    }
+  };
+#define UWM_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+  if (t0 < t1) {
+#pragma unroll
+    for (int i = 0; i < YI; ++i) y_dma(t0, 0, i);
+    patch_load(t0);
+    patch_store(0);
+  }
+  __syncthreads();
+
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    const int tn = t + 1 < t1 ? t + 1 : t;          // last stage: harmless re-fetch into the dead buffers
+    const float* ys = Ys + cur * kYs;
+    const float* ps = Ps + cur * kPP * kCW;
+    if constexpr (NCA == 1) {
+      // TA = 32 (3 workgroups per CU, registers to spare): software-pipelined operand path.  Raw LDS values of the NEXT
+      // 4-tile block are read one MFMA group ahead of their first use, so no MFMA waits for a read it has just issued.
+      read_B(ps, 0);
+      read_A(ys, 0, 0);
+      transform_B(V);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) read_B(ps, ks + 1);             // R0: raw input patch of the next block
+        UWM_FENCE();
+        // R1: the MFMA group.  Stage-boundary work rides on it: block 0 carries the next stage's patch loads, blocks 1 / 2
+        // its dY DMA, block 3 the patch stores (their loads are >= 2 blocks old by then)
+        if (ks == 0) patch_load(tn);
+        if (ks == 1) y_dma(tn, cur ^ 1, 0);
+        if (ks == 2) y_dma(tn, cur ^ 1, 1);
+        mfma_group(0);
+        if (ks == 3) patch_store(cur ^ 1);
+        UWM_FENCE();
+        if (ks < 3) { read_A(ys, ks + 1, 0); transform_B(V); }     // R2: next block's dY + input transform
+      }
+    } else {
+      // TA = 64 (2 workgroups per CU, ~220 registers): the fully fenced pipeline above spills here (measured 133 vs 123 us
+      // on layer3).  Lighter form: the raw input patch of the NEXT block is read right after this block's transform has
+      // consumed the registers, i.e. a whole block (32 MFMAs) ahead of its use; this block's dY reads sit above the input
+      // transform, whose 32 VALU ops cover their latency.  Inside a block the compiler interleaves transforms and MFMAs.
+      read_B(ps, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks == 0) patch_load(tn);
+        if (ks == 1) { y_dma(tn, cur ^ 1, 0); y_dma(tn, cur ^ 1, 1); }
+        if (ks == 2) { y_dma(tn, cur ^ 1, 2); y_dma(tn, cur ^ 1, 3); }
+        read_A(ys, ks, 0);
+        read_A(ys, ks, 1);
+        transform_B(V);
+        if (ks < 3) read_B(ps, ks + 1);
+        mfma_group(0);
+        mfma_group(1);
+        if (ks == 3) patch_store(cur ^ 1);
+        UWM_FENCE();
+      }
+    }
+    __syncthreads();
+  }
+#undef UWM_FENCE
+
+  // ---------------- epilogue: dW = G^T Z G, all in registers ----------------
+  // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: over i then over j: (z0 + h(z1+z2), h(z1-z2), h(z1+z2) + z3), h = 1/2
+  float* const dst = a.nsplit > 1 ? a.part + (size_t)split * a.wrows * a.Kpad : a.dw;
+  const bool direct = a.nsplit <= 1;
+#pragma unroll
+  for (int q = 0; q < NCA; ++q) {
+    f4 R[3][4];                                      // rows r = 0..2 (i transformed), columns j = 0..3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f4 sp_ = 0.5f * (acc[1][j][q] + acc[2][j][q]), sm_ = 0.5f * (acc[1][j][q] - acc[2][j][q]);
+      R[0][j] = acc[0][j][q] + sp_; R[1][j] = sm_; R[2][j] = sp_ + acc[3][j][q];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const f4 sp_ = 0.5f * (R[r][1] + R[r][2]), sm_ = 0.5f * (R[r][1] - R[r][2]);
+      const f4 w3[3] = {R[r][0] + sp_, sm_, sp_ + R[r][3]};
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = a0 + (wca + q) * 16 + lq * 4 + e;
+          if (row < a.wrows) {
+            float* p = dst + (size_t)row * a.Kpad + (r * 3 + s_) * a.Ctot + cc * kCW + wcb * 16 + li;
+            *p = direct ? *p + w3[s_][e] : w3[s_][e];
+          }
+        }
+    }
+  }
+}
+
+// dw[i] += part[0][i] + part[1][i] + ... in split order (16-byte units); n4 = wrows * Kpad / 4
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n4, float* __restrict__ dw) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f4 s = *(const f4*)(part + i * 4);
+    for (int k = 1; k < nsplit; ++k) s += *(const f4*)(part + ((size_t)k * n4 + i) * 4);
+    *(f4*)(dw + i * 4) += s;
+  }
+}
+
+constexpr int kMaxPartBlocks = 1024;          // workgroups of a split launch: bounds the partial-sum scratch
+size_t wgrad_wino_scratch_floats() { return (size_t)kMaxPartBlocks * 64 * kCW * 9; }
+
+static float* op_scratch() {                  // single-operator entry points (no workspace): one cached buffer per device
+  static float* buf[64] = {nullptr};
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!buf[dev] && hipMalloc((void**)&buf[dev], wgrad_wino_scratch_floats() * sizeof(float)) != hipSuccess) { buf[dev] = nullptr; (void)hipGetLastError(); }
+  return buf[dev];
 }
 
 template <int TA>
 static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nblocks) {
   size_t lds = (size_t)(2 * 64 * TA + 2 * kPP * kCW) * sizeof(float);
-  const size_t rl = (size_t)9 * TA * kCW * sizeof(float);
-  if (lds < rl) lds = rl;
-  static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
-  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_wino_kernel<TA>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_wino_kernel<TA>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
+  static const bool v1 = getenv("UWM_WGRAD_V1") != nullptr;        // experiments: the round-1 row-per-wave kernel for every TA
+  if (TA == 16 || v1) {
+    const size_t rl = (size_t)9 * TA * kCW * sizeof(float);
+    if (lds < rl) lds = rl;
+    static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
+    { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_wino_kernel<TA>, lds); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_wino_kernel<TA>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
+  } else if constexpr (TA != 16) {
+    static DevOnce lds_attr;
+    { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_wino2_kernel<TA>, lds); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_wino2_kernel<TA>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
+  }
+  if (a.nsplit > 1) {
+    const size_t n4 = (size_t)a.wrows * a.Kpad / 4;
+    unsigned nb = (unsigned)((n4 + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)a.part, a.nsplit, n4, a.dw);
+  }
   return hipGetLastError();
 }
 
 bool wgrad_wino_applicable(const WgradArgs& a) {
   const int TA = a.Cout >= 64 ? 64 : a.Cout;
   return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
-         (TA == 64 || TA == 32 || TA == 16) && a.Cout % TA == 0 && a.wrows <= a.Cout &&
+         (TA == 64 || TA == 32 || TA == 16) && a.Cout % TA == 0 && a.wrows <= a.Cout && a.Kpad == 9 * a.Ctot &&
          a.Hl == a.Ho && a.Wl == a.Wo && (a.Ho % kSH) == 0 && (a.Wo % kSW) == 0;
 }
 
 hipError_t launch_wgrad_wino(const WgradArgs& a0, hipStream_t st) {
   WgradArgs a = a0;
   if (!wgrad_wino_applicable(a)) return hipErrorInvalidValue;
-  const int TA = a.Cout >= 64 ? 64 : a.Cout;
+  int TA = a.Cout >= 64 ? 64 : a.Cout;
+  static const int force_ta = getenv("UWM_WW_TA") ? atoi(getenv("UWM_WW_TA")) : 0;      // experiments
+  if (force_ta && TA > force_ta && a.Cout % force_ta == 0) TA = force_ta;
   const int nchunk = a.Ctot / kCW, tilesA = a.Cout / TA;
   const int nstages = a.N * (a.Ho / kSH) * (a.Wo / kSW);
-  // same cost model as wgrad_patch: rounds x (stages per workgroup + epilogue worth E stages)
+  // cost model: rounds x (stages per workgroup + epilogue worth E stages); a split launch is capped at kMaxPartBlocks
+  // workgroups (the partial-sum scratch) and, from 8 splits on, uses a multiple of 8 of them (one XCD per split)
   const int cus = device_cu_count();
   const int pairs = nchunk * tilesA;
-  const int slots = cus * 2;
-  const double E = TA == 64 ? 4.0 : (TA == 32 ? 2.0 : 1.0);
+  const int slots_per_cu = TA == 64 ? 2 : 3;
+  const double E = TA == 64 ? 2.0 : 1.0;
+  const int slots = cus * slots_per_cu;
   int nsplit = 1; double best = 1e30;
   for (int ns = 1; ns <= nstages && ns <= 2048; ++ns) {
     const int tp = (nstages + ns - 1) / ns;
-    const int nsr = (nstages + tp - 1) / tp;
+    int nsr = (nstages + tp - 1) / tp;
+    if (nsr >= 8) nsr = (nsr + 7) & ~7;
+    if (nsr > nstages) continue;
     const long blocks = (long)pairs * nsr;
+    if (nsr > 1 && blocks > kMaxPartBlocks) break;
+    const int tpe = (nstages + nsr - 1) / nsr;
     const long rounds = (blocks + slots - 1) / slots;
-    const double cost = (double)rounds * (tp + E);
+    const double cost = (double)rounds * (tpe + E) + 0.02 * nsr;     // (+ the reduce pass reads nsr partial tiles)
     if (cost < best - 1e-9) { best = cost; nsplit = nsr; }
   }
   int tps = (nstages + nsplit - 1) / nsplit;
-  nsplit = (nstages + tps - 1) / tps;
+  if (nsplit < 8) nsplit = (nstages + tps - 1) / tps;               // (a multiple of 8 keeps its empty tail splits: t0 >= t1)
   a.nsplit = nsplit; a.msplit = tps;
+  if (nsplit > 1) {
+    if (!a.part || a.part_floats < (size_t)nsplit * a.wrows * a.Kpad) { a.part = op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); }
+    if (!a.part || a.part_floats < (size_t)nsplit * a.wrows * a.Kpad) return hipErrorOutOfMemory;
+  }
   const int nblocks = nsplit * tilesA * nchunk;
   switch (TA) {
     case 64: return launch_ww<64>(a, st, 22, nblocks);
