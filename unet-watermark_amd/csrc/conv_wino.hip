@@ -224,11 +224,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     const int xi = L / (NI * 32), within = L - xi * (NI * 32);
     uoff[i] = xi * nCb * 128 + within * 4;
   }
-  auto u_dma = [&](int cc, int buf) {
+  auto u_dma = [&](int cc, int buf, int i0, int i1) {      // pieces [i0, i1) of the chunk's UR wave-instructions
     const float* const uc = ug + (size_t)cc * 16 * nCb * 128;
 #pragma unroll
-    for (int i = 0; i < UR; ++i) glds16(uc + uoff[i], Us + buf * kUs + (i * 4 + wave) * 256);
+    for (int i = 0; i < UR; ++i)
+      if (i >= i0 && i < i1) glds16(uc + uoff[i], Us + buf * kUs + (i * 4 + wave) * 256);
   };
+  // NI <= 2: the next chunk's U arrives in 1-KB LDS-DMA pieces issued BETWEEN the MFMA groups of this chunk (layer3-sized
+  // launches: 130 -> 120 us, conv_wino<32> 193 -> 177 us in the step); the last group carries none, so every piece has
+  // >= 16 MFMAs to land.  NI = 4 keeps all 8 pieces with group 0: spreading them measured 2-4 % SLOWER there (282 -> 293 us
+  // on decoder block 0 conv1; 6.2 -> 6.4 ms per step) — its 16-MFMA groups are long enough that the issue cost was
+  // already hidden by the second resident workgroup.
+  constexpr int kD0 = NI == 4 ? UR : (UR * 3 + 7) / 8, kD1 = NI == 4 ? UR : (UR * 6 + 7) / 8;      // pieces [0,kD0) with group 0, [kD0,kD1) with 1, rest with 2
 
   // ---- per-lane addresses of the B^T row pair this wave combines: r = d[ra] + sg * d[rb]
   const int ra = (wave == 0) ? 0 : (wave == 2 ? 2 : 1);
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   const int ufrag = wave * 4 * NI * 128 + lq * 32 + t16 * 2;
 
   const int nchunk = a.Ctot >> 3;
-  u_dma(0, 0);
+  u_dma(0, 0, 0, UR);
   patch_load(0);
   patch_store(0);
   __syncthreads();
@@ -257,9 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   for (int cc = 0; cc < nchunk; ++cc) {
     const int cur = cc & 1, nxt = cur ^ 1;
     const int cn = cc + 1 < nchunk ? cc + 1 : cc;   // last chunk: harmless re-fetch into the dead buffer
-    if (!(dbg & 2)) u_dma(cn, nxt);
-    if (!(dbg & 4)) patch_load(cn);
-    __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ABOVE the MFMA block (hipcc otherwise sinks it to the end)
+    if (!(dbg & 4)) patch_load(cn);                 // (fenced into group 0 below: hipcc otherwise sinks it to the end)
 
     // (B^T d B)[wave][0..3] for both tile blocks, in registers
     const float* const pc = Ps + cur * 2 * kPlane;
@@ -280,6 +285,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     for (int cb = 0; cb < NI; ++cb) wf[0][cb] = (dbg & 16) ? (f2){1.f, 1.f} : *(const f2*)(uc + cb * 128);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (!(dbg & 2)) {
+        if (j == 0) u_dma(cn, nxt, 0, kD0);
+        if (j == 1) u_dma(cn, nxt, kD0, kD1);
+        if (j == 2) u_dma(cn, nxt, kD1, UR);
+      }
       if (j < 3) {
 #pragma unroll
         for (int cb = 0; cb < NI; ++cb) wf[(j + 1) & 1][cb] = (dbg & 16) ? (f2){1.f, 1.f} : *(const f2*)(uc + ((j + 1) * NI + cb) * 128);
@@ -292,8 +302,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
           for (int tb = 0; tb < 2; ++tb)
             if (!(dbg & 1)) acc[j][tb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j & 1][cb][e], V[tb][j][e], acc[j][tb][cb], 0, 0, 0);
             else acc[j][tb][cb][0] += wf[j & 1][cb][e] * V[tb][j][e];
+      __builtin_amdgcn_sched_barrier(0);            // one fence per MFMA group: pins the DMA pieces / prefetch to their group
     }
-    __builtin_amdgcn_sched_barrier(0);
     if (!(dbg & 4)) patch_store(nxt);
     if (!(dbg & 64)) __syncthreads();                    // next chunk's U (LDS-DMA) and patch have landed; everyone is done with `cur`
   }
