@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 WINO_RATIO = 2.25            # direct-conv multiplies per Winograd F(2x2,3x3) multiply (36 / 16)
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (alt_modes only)
 
 
 def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Unet"):
@@ -91,6 +92,22 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
             if float(g2.norm()) > 0 and float(g1.norm()) > 0:
                 cmin = min(cmin, float(g1 @ g2 / (g1.norm() * g2.norm())))
         out["min_grad_cosine_vs_cpu_ref"] = round(cmin, 6)
+        # the opt-in precision modes on the same batch / weights / oracle run
+        alt = {}
+        for mode in ("bf16x3", "bf16x3_all"):
+            hm.load_state_dict(ref0.state_dict()); hm.set_precision(mode)
+            for p_ in hm.parameters():
+                p_.grad = None
+            o2 = hm(x.to(dev)); l2 = ch(o2, t.unsqueeze(1).to(dev)); l2.backward()
+            c2 = 1.0
+            for name, p_ in hm.named_parameters():
+                g1, g2 = p_.grad.detach().cpu().double().flatten(), gref[name].grad.double().flatten()
+                if float(g2.norm()) > 0 and float(g1.norm()) > 0:
+                    c2 = min(c2, float(g1 @ g2 / (g1.norm() * g2.norm())))
+            alt[mode] = {"logit_max_abs_err_vs_cpu_ref": float(f"{float((o2.detach().cpu() - lr_).abs().max()):.3e}"),
+                         "min_grad_cosine_vs_cpu_ref": round(c2, 6)}
+        hm.set_precision("f32")
+        out["alt_modes_parity"] = alt
     except Exception as e:                      # never let the checker break the bench line
         out["mask_iou_vs_cpu_ref"] = None
         out["mask_note"] = f"not computed: {type(e).__name__}: {e}"
@@ -142,6 +159,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
     ap.add_argument("--prof-steps", type=int, default=5, help="timed steps (the last ones) whose conv launches carry HIP event pairs")
+    ap.add_argument("--alt-steps", type=int, default=20, help="timed steps per opt-in precision mode (alt_modes; 0 = skip; N=1 only)")
     ap.add_argument("--serial-steps", type=int, default=3,
                     help="extra UNTIMED steps after the timed region with the wgrad side stream off, to report the "
                          "dominant kernel alone next to its in-step (co-resident) figure (0 = skip)")
@@ -220,6 +238,41 @@ def main():
         ents_s = collect_prof(L, args.serial_steps)
         L.lib().uwm_set_side_stream(model._h, 1)
 
+    # opt-in precision modes (NOT part of `value`): the same step with uwm_set_precision(bf16x3 | bf16x3_all)
+    alt_modes = None
+    if args.alt_steps > 0 and rank == 0 and world == 1:
+        alt_modes = {}
+        for mode in ("bf16x3", "bf16x3_all"):
+            model.set_precision(mode)
+            for _ in range(3):
+                trainer.step(x, t)
+            torch.cuda.synchronize(dev)
+            ta = time.perf_counter()
+            for _ in range(args.alt_steps):
+                la = trainer.step(x, t)
+            torch.cuda.synchronize(dev)
+            dta = time.perf_counter() - ta
+            L.lib().uwm_prof_enable(1)
+            for _ in range(3):
+                trainer.step(x, t)
+            torch.cuda.synchronize(dev)
+            L.lib().uwm_prof_enable(0)
+            ea = collect_prof(L, 3).get("conv_wino_x3_kernel")
+            ent = {"value": round(n * args.alt_steps / dta, 2), "unit": "images/s", "ms_per_step": round(1e3 * dta / args.alt_steps, 3),
+                   "steps": args.alt_steps, "loss": round(float(la[0].item()), 6),
+                   "dtype": ("bf16x3 on the dgrad products of the 3x3 stride-1 layers (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate); "
+                             "forward, weight gradients, BatchNorm, loss, optimizer: f32") if mode == "bf16x3" else
+                            "bf16x3 on forward AND dgrad products of the 3x3 stride-1 layers; weight gradients and the rest: f32"}
+            if ea:      # roofline of the split-bf16 kernel: 3 executed bf16 MFMA FLOPs per Winograd-domain FLOP, against the bf16 peak
+                ex = 3.0 * ea["_exec"] / ea["_ms"] / 1e9
+                ent["roofline"] = {"bound": "mfma", "kernel": "conv_wino_x3_kernel", "achieved": round(ex, 1), "peak": BF16_MATRIX_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(ex / BF16_MATRIX_PEAK_TFLOPS, 4), "avg_launch_us": ea["avg_us"],
+                                   "launches_per_step": ea["launches_per_step"], "algorithmic_tflops": ea["algorithmic_tflops"],
+                                   "note": "executed = 3 x (direct-conv FLOPs / 2.25) on v_mfma_f32_16x16x16_bf16; the kernel is bound by the "
+                                           "fp32 input transform + bf16 split on the VALU and the filter stream, not by the bf16 MFMA pipe"}
+            alt_modes[mode] = ent
+        model.set_precision("f32")
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -296,8 +349,13 @@ def main():
                 "traffic": traffic,
                 "profiled_steps": f"last {prof_steps} of the {args.steps} timed steps"}
             out["kernels"] = [{k: v for k, v in e.items() if not k.startswith("_")} for e in kernels]
+        if alt_modes is not None:
+            out["alt_modes"] = alt_modes
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch)
+            if alt_modes is not None:
+                for mode, par in out["cpu_baseline"].pop("alt_modes_parity", {}).items():
+                    alt_modes[mode]["parity_vs_cpu_ref"] = par
         print(json.dumps(out), flush=True)
     if world > 1 or force_ddp:
         dist.barrier(device_ids=[local_rank])

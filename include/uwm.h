@@ -49,6 +49,7 @@ enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* 
 enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
        UWM_KIND_BN_MEAN = 4, UWM_KIND_BN_VAR = 5 };
 enum { UWM_ARENA_PARAM = 0, UWM_ARENA_BUFFER = 1 };
+enum { UWM_PREC_F32 = 0, UWM_PREC_BF16X3 = 1, UWM_PREC_BF16X3_ALL = 2 };       /* uwm_set_precision */
 
 /* mirrors smp.Unet(encoder_name, encoder_depth=5, decoder_channels, in_channels, classes) */
 typedef struct {
@@ -169,6 +170,20 @@ int  uwm_preprocess_mask_u8(const uint8_t* masks, int N, int H, int W, int thres
 int  uwm_set_winograd(int on);
 int  uwm_set_winograd_mode(uwm_handle h, int mode);
 int  uwm_get_winograd_mode(uwm_handle h);
+/* Precision mode, per handle.  UWM_PREC_F32 (default): every product on the exact-fp32 matrix instruction.
+ * "bf16x3" arithmetic takes a product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi over bf16 halves (hi = bf16(x), lo = bf16(x - hi))
+ * of the fp32 operands with fp32 accumulation: ~17 mantissa bits per operand on 3 bf16 matrix instructions at 16x the fp32
+ * rate (conv_wino_x3.hip).  Parameters, activations, accumulators, BatchNorm, loss, weight gradients and optimizer state
+ * stay fp32 in every mode.
+ *   UWM_PREC_BF16X3      the BACKWARD data-gradient (dgrad) products of the 3x3 stride-1 layers with whole 16-channel
+ *                        chunks.  The forward is untouched, so logits are the fp32 mode's bit for bit and the 1e-3 bar
+ *                        against the fp32 CPU reference holds at every depth; gradients meet the fp32 mode's bars.
+ *   UWM_PREC_BF16X3_ALL  forward products of those layers as well.  Measured logit error vs the fp32 CPU reference:
+ *                        < 1e-3 on resnet18 / efficientnet-b4, 1.6e-3 on resnet34 (2x256x192) — outside BASELINE's bar on
+ *                        the deeper encoders, offered for what the reference itself does on a GPU: reduced-precision
+ *                        training (fp16 autocast + GradScaler, /root/reference/src/train.py:75,89-98). */
+int  uwm_set_precision(uwm_handle h, int mode);
+int  uwm_get_precision(uwm_handle h);
 /* EfficientNet encoders only: stochastic depth ("drop connect") of the MBConv blocks in training mode.  `rowscale` is a
  * device array [uwm_num_mbconv_blocks][N] holding, per block and sample, keep/(1 - p_block) with keep in {0,1}; the host
  * draws it each step (uwm_mbconv_drop_rate gives p_block; blocks without identity skip ignore their row).  NULL (the
@@ -216,7 +231,8 @@ typedef struct {
 /* y[N][Ho][Wo][Cout] = conv(cat(s0,s1), w) ; w [Cout][Kpad] packed (k = tap*Ctot + c).
  * stats (2*Cout doubles: sum, sumsq; pre-zeroed) may be NULL.
  * cfg: -1 = the library's routing; 0..5 implicit-GEMM tile configs; 100+BN direct patch kernel; 200 16-channel patch
- * kernel; 300 (+BN, 308 = 8-wave) Winograd F(2x2,3x3); 500 segmentation-head streaming kernel (tests / timing). */
+ * kernel; 300 (+BN, 308 = 8-wave) Winograd F(2x2,3x3); 400 Winograd in bf16x3 arithmetic; 500 segmentation-head streaming
+ * kernel (tests / timing). */
 int  uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
                  int pad, int N, int Cout, const float* bias, float* y, double* stats, int cfg, uwm_stream stream);
 /* dx[N][H][W][Cin] = conv_transpose(dy[N][Ho][Wo][Cout], wd) (+addend, *relu-mask) ; wd [Cin][KpadD] */

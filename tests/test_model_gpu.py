@@ -87,6 +87,73 @@ def test_train_forward_backward_parity(cuda, enc, n, h, w):
     assert float(m.flat_grads().abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("arch,enc,n,h,w", [("Unet", "resnet18", 4, 128, 160), ("Unet", "resnet34", 2, 256, 192),
+                                            ("UnetPlusPlus", "resnet34", 2, 128, 192), ("Unet", "resnet50", 4, 128, 160),
+                                            ("Unet", "efficientnet-b4", 4, 128, 128)])
+def test_bf16x3_precision_mode_meets_the_fp32_bars(cuda, arch, enc, n, h, w):
+    """The opt-in second precision mode (uwm_set_precision(h, UWM_PREC_BF16X3): 3-term split-bf16 products on the backward
+    data-gradient convolutions, fp32 everywhere else) against the fp32 CPU oracle under the SAME bars as the fp32 mode, on
+    every encoder and both decoders: logits <= 1e-3 (they are the fp32 mode's bit for bit: the forward is untouched), loss
+    1e-5, per-tensor gradient cosine / L2.  The mode is per handle and switches back.
+    (The reference's GPU path is fp16 autocast: /root/reference/src/train.py:75,89-98.)"""
+    import unet_watermark_amd as U
+    from unet_watermark_amd import _lib as L
+    from oracle import unet_oracle as O
+    m, ref = _pair(enc, dev=cuda, arch=arch)
+    assert m.precision == "f32" and L.lib().uwm_get_precision(m._h) == 0
+    with pytest.raises(ValueError):
+        m.set_precision("fp8")
+    if enc == "efficientnet-b4":
+        m.drop_connect = False
+    x, t = O.synthetic_batch(n, h, w, seed=7)
+    m.train(); ref.train()
+    crit_ref = O.CombinedLoss([O.BCEWithLogits(), O.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    crit = U.CombinedLoss([U.BCEWithLogitsLoss(), U.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    out_ref = ref(x); loss_ref = crit_ref(out_ref, t.unsqueeze(1)); loss_ref.backward()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    out_f32 = m(x.to(cuda)); crit(out_f32, t.unsqueeze(1).to(cuda)).backward()
+    g_f32 = m.flat_grads().clone()
+    m.load_state_dict(sd0)                                      # undo the running-statistics update of that forward
+    m.set_precision("bf16x3")
+    assert L.lib().uwm_get_precision(m._h) == 1
+    for p in m.parameters():
+        p.grad = None
+    out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda)); loss.backward()
+    assert torch.equal(out.detach(), out_f32.detach())          # forward untouched by this mode
+    assert float((out.detach().cpu() - out_ref.detach()).abs().max()) < LOGIT_TOL
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    if enc == "resnet50":
+        _grad_check(m, ref, l2_rel=7e-2, cos_min=0.9975)        # the fp32 mode's own bars for this 53-BatchNorm-deep net
+    elif enc == "efficientnet-b4":
+        _effb4_grad_check(m, ref)
+    else:
+        _grad_check(m, ref)
+    g_x3 = m.flat_grads()
+    assert not torch.equal(g_x3, g_f32)                          # the mode really changes the backward arithmetic ...
+    assert float((g_x3 - g_f32).norm() / g_f32.norm()) < 2e-2    # ... by rounding noise only
+    m.set_precision("f32")
+    assert L.lib().uwm_get_precision(m._h) == 0
+
+
+@pytest.mark.parametrize("enc,bar", [("resnet18", 1e-3), ("resnet34", 3e-3)])
+def test_bf16x3_all_forward_error_is_what_the_header_says(cuda, enc, bar):
+    """UWM_PREC_BF16X3_ALL (forward products split as well) is offered outside BASELINE's parity claim: its logit error
+    against the fp32 oracle is measured here — inside 1e-3 on resnet18, 1.6e-3 on resnet34 at 2x256x192 (bar 3e-3) — so the
+    header's statement stays true; gradients still meet the fp32 bars."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    m, ref = _pair(enc, dev=cuda)
+    m.set_precision("bf16x3_all")
+    x, t = O.synthetic_batch(2, 256, 192, seed=7)
+    m.train(); ref.train()
+    crit_ref = O.DiceLoss(smooth=1e-5); crit = U.DiceLoss(mode="binary", smooth=1e-5)
+    out_ref = ref(x); crit_ref(out_ref, t.unsqueeze(1)).backward()
+    out = m(x.to(cuda)); crit(out, t.unsqueeze(1).to(cuda)).backward()
+    err = float((out.detach().cpu() - out_ref.detach()).abs().max())
+    assert err < bar, err
+    _grad_check(m, ref)
+
+
 @pytest.mark.parametrize("enc,n,h,w", [("resnet18", 4, 128, 160), ("resnet34", 2, 256, 192), ("resnet18", 4, 64, 64)])
 def test_unetplusplus_train_forward_backward_parity(cuda, enc, n, h, w):
     """UnetPlusPlus (the reference's default MODEL.NAME): dense decoder grid, several consumers per tensor in the

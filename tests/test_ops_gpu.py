@@ -90,6 +90,53 @@ def test_conv_winograd_8wave(cuda, cin, cout):
     _conv_case(cuda, 1, cin, cout, 17, 33, 3, 1, 1, cfg=308, lazy=True, seed=2)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(16, 32, 16, 32), (32, 40, 24, 48), (64, 64, 32, 32), (48, 16, 8, 16), (128, 96, 16, 16)])
+def test_conv_winograd_bf16x3(cuda, cin, cout, h, w):
+    """conv_wino_x3 (cfg 400): Winograd F(2x2,3x3) with every product as a 3-term split-bf16 MFMA sum (the opt-in bf16x3
+    precision mode) against F.conv2d in fp32 — over-hanging Cout (40, 96 on 32-channel tiles), partial pixel tiles, bias,
+    BatchNorm statistics.  Bar: 1e-4 of the output scale (measured ~1e-5: ~16 mantissa bits per operand)."""
+    L = lib()
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    n = 2
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    y = torch.nn.functional.conv2d(x, wt, bias, padding=1)
+    xd = nhwc(x.to(cuda)); wp, kpad = pack_w(wt.to(cuda)); cp = rup(cout, 4)
+    bp = torch.zeros(cp, device=cuda); bp[:cout] = bias.to(cuda)
+    out = torch.full((n, h, w, cp), float("nan"), device=cuda)
+    stats = torch.zeros(2 * cp, dtype=torch.float64, device=cuda)
+    s0 = src(xd)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), cout, kpad, 3, 3, 1, 1, n, cp, P(bp), P(out), P(stats), 400, stream()))
+    got = nchw(out.cpu(), cout)
+    err = float((got - y).abs().max()); scale = max(1.0, float(y.abs().max()))
+    assert err < 1e-4 * scale, (err, scale)
+    assert torch.isfinite(out[..., :cout]).all()
+    ssum = stats[:cout].cpu(); ref_sum = y.double().sum((0, 2, 3))
+    assert torch.allclose(ssum, ref_sum, rtol=1e-4, atol=1e-3 * float(ref_sum.abs().max() + 1))
+
+
+def test_conv_winograd_bf16x3_lazy_upsample_concat(cuda):
+    """the bf16x3 kernel behind the decoder's two-source loader: nearest x2 upsample of a lazily normalised + ReLU-ed tensor
+    concatenated with a skip tensor (16-channel chunk boundary at the concat)."""
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    n, c0, c1, cout, h, w = 2, 32, 16, 32, 16, 32
+    a = torch.randn(n, c0, h // 2, w // 2, generator=g); sk = torch.randn(n, c1, h, w, generator=g)
+    sc = torch.rand(c0, generator=g) + 0.5; sh = torch.randn(c0, generator=g) * 0.3
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
+    act = torch.relu(a * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    xin = torch.cat([torch.nn.functional.interpolate(act, scale_factor=2, mode="nearest"), sk], 1)
+    y = torch.nn.functional.conv2d(xin, wt, None, padding=1)
+    ad, skd = nhwc(a.to(cuda)), nhwc(sk.to(cuda)); wp, kpad = pack_w(wt.to(cuda))
+    scd, shd = sc.to(cuda), sh.to(cuda)
+    out = torch.empty(n, h, w, cout, device=cuda)
+    s0 = src(ad, scd, shd, relu=1, up=1); s1 = src(skd)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), C.byref(s1), P(wp), cout, kpad, 3, 3, 1, 1, n, cout, None, P(out), None, 400, stream()))
+    err = float((nchw(out.cpu(), cout) - y).abs().max())
+    assert err < 1e-4 * max(1.0, float(y.abs().max())), err
+
+
 def test_conv_winograd_error_vs_fp64(cuda):
     """Winograd's transforms cost a little accuracy; measured against an fp64 convolution the error must stay
     within 4x that of the direct fp32 kernel (and far inside the 1e-3 logit budget)."""

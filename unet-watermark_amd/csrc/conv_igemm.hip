@@ -315,14 +315,19 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
             (int)(cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)), a.flops * 1e-9);
   if (cfg == 500) return launch_conv_head(a, st);
+  if (cfg == 400) return launch_conv_wino_x3(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
-  if (a.out_up) return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;   // fused concat split: Winograd epilogue only
+  if (a.out_up) {                                                  // fused concat split: Winograd epilogues only
+    if (a.prec == 1) return launch_conv_wino_x3(a, st);
+    return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;
+  }
   if (cfg == 200) return launch_conv_patch16(a, st);
   static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
   if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);
   if (cfg < 0 && !no_head && conv_head_dgrad_applicable(a)) return launch_conv_head_dgrad(a, st);      // few channels -> <= 4 classes: HBM streaming kernel
   // 16-channel inputs at full resolution are HBM-bound: the one-barrier direct kernel beats the Winograd pipeline there
-  if (cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a)) return launch_conv_wino(a, st);
+  if (cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a))
+    return a.prec == 1 ? launch_conv_wino_x3(a, st) : launch_conv_wino(a, st);      // prec 1: the bank behind a.wu is a bf16x3 one
   if (cfg >= 100) return launch_conv_patch(a, st, cfg - 100);
   if (cfg < 0 && conv_patch16_applicable(a)) return launch_conv_patch16(a, st);
   if (cfg < 0 && conv_patch_applicable(a)) {

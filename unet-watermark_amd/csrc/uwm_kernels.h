@@ -72,6 +72,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
   int wino;                  // Winograd mode of this launch: 0 = process default (uwm_set_winograd), else mode + 1 (per-handle: uwm_set_winograd_mode)
+  int prec;                  // 1: wu is a bf16x3 bank (conv_wino_x3.hip layout) and the launch goes to the split-bf16 kernel; 0: fp32
 };
 
 struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = tap*Ctot + c)
@@ -94,7 +95,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 31 };   // 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 32 };   // 31 = conv_wino_x3 (bf16x3) ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -143,6 +144,10 @@ hipError_t launch_wino_weights(const float* w, int wrows, int Kpad, int Ctot, in
 struct WinoJob { const float* w; float* ut; int rows, chans, Kpad, mode, src_rows, pad_; };
 struct WinoJobs { WinoJob j[40]; int n; };
 hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st);   // every layer's transform in one launch
+// bf16x3 precision mode (conv_wino_x3.hip): split-bf16 filter banks (same size as the fp32 ones) and the conv kernel; force_cfg 400
+hipError_t launch_wino_weights_x3_multi(const WinoJobs& jobs, hipStream_t st);
+bool conv_wino_x3_applicable(const ConvArgs& a);
+hipError_t launch_conv_wino_x3(const ConvArgs& a, hipStream_t st);
 // process default (UWM_WINOGRAD / uwm_set_winograd): used by the single-operator entry points and by handles created later
 bool winograd_enabled();
 void winograd_set_mode(int mode);   // 0 off, 1 auto, 2 = tests: take the 8-wave variant wherever its shape rules allow

@@ -50,6 +50,10 @@ struct ConvL {
   size_t wu_off, wud_off;          // workspace floats: Winograd-transformed weights (forward / dgrad); 0 = none
   bool wino() const { return k == 3 && stride == 1 && pad == 1 && (CinP & 7) == 0; }
   bool wino_d() const { return dgrad && k == 3 && stride == 1 && pad == 1 && (CoutP & 7) == 0; }
+  int c0 = 0;                      // channels of the FIRST source of this conv's input (decoder conv1: the up-sampled tensor; else CinP)
+  // bf16x3 precision mode: whole 16-channel chunks on either side of the concat (conv_wino_x3.hip)
+  bool x3() const { return wino() && (CinP & 15) == 0 && (c0 & 15) == 0; }
+  bool x3_d() const { return wino_d() && (CoutP & 15) == 0; }
 };
 // encoder residual block.  BasicBlock: c1 3x3(stride) -> c2 3x3, c3 = -1.  Bottleneck: c1 1x1 -> c2 3x3(stride) -> c3 1x1(x4).
 struct BlockL { int c1, c2, cd, c3 = -1, stride = 1, Cin = 0, Cout = 0; int last() const { return c3 >= 0 ? c3 : c2; } };
@@ -68,6 +72,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   std::vector<size_t> y, g;         // per conv: raw output / its gradient buffer (float offsets)
   std::vector<int> oh, ow;          // per conv: output height / width
   int wino_mode = 1;                // the handle's Winograd mode when this plan was made (0 off, 1 auto, 2 = 8-wave variant wherever allowed)
+  int prec = 0;                     // the handle's precision mode (UWM_PREC_*: 0 fp32, 1 bf16x3 dgrad convs, 2 bf16x3 forward + dgrad convs)
   bool wino_ok(size_t ci) const { return wino_mode != 0 && oh[ci] >= 8 && ow[ci] >= 16; }   // conv_wino tile fits
   std::vector<size_t> xn, gx;       // per encoder block: residual output / its gradient
   std::vector<size_t> dcat, gskip;  // per decoder block (UnetPlusPlus: dcat[0] = shared scratch, gskip[0..3] = f4,f3,f2,f1 accumulators)
@@ -115,6 +120,7 @@ struct uwm_model {
   bool packed_in_fwd = false;         // dgrad weight repacks were enqueued on the side stream by the last forward
   int pack_mode = -1;                 // Winograd mode those repacks were made for
   int wino_mode = 1;                  // per-handle Winograd mode (uwm_set_winograd_mode); starts as the process default
+  int prec = 0;                       // per-handle precision mode (uwm_set_precision): UWM_PREC_F32 | UWM_PREC_BF16X3 | UWM_PREC_BF16X3_ALL
   int device = -1;                    // HIP device the bound arenas live on (uwm_bind)
   int nstages = 5;                    // backward stages = gradient buckets (head+decoder, then four encoder groups)
   bool hwq_warned = false;
@@ -130,7 +136,7 @@ static int add_conv(uwm_model* m, const std::string& name, int Cin, int Cout, in
   c.k = k; c.stride = stride; c.pad = pad; c.stage = stage; c.dgrad = dgrad;
   c.Kpad = (int)rup((long long)k * k * c.CinP, 32);
   c.KpadD = (int)rup((long long)k * k * c.CoutP, 32);
-  c.w_off = -1; c.bias_off = bias ? 0 : -1; c.wd_off = 0; c.wu_off = c.wud_off = 0;
+  c.w_off = -1; c.bias_off = bias ? 0 : -1; c.wd_off = 0; c.wu_off = c.wud_off = 0; c.c0 = c.CinP;
   c.bn = bn_name.empty() ? -1 : add_bn(m, bn_name, Cout, stage, bn_eps, bn_mom);
   m->convs.push_back(c); return (int)m->convs.size() - 1;
 }
@@ -230,6 +236,7 @@ static int build_model(uwm_model* m) {
       char pre[64]; snprintf(pre, sizeof(pre), "decoder.blocks.%d", i);
       DecL dl; dl.C0 = prev; dl.C1 = skip;
       dl.c1 = add_conv(m, std::string(pre) + ".conv1.0", prev + skip, out, 3, 1, 1, 0, true, std::string(pre) + ".conv1.1");
+      m->convs[dl.c1].c0 = prev;
       dl.c2 = add_conv(m, std::string(pre) + ".conv2.0", out, out, 3, 1, 1, 0, true, std::string(pre) + ".conv2.1");
       m->dec.push_back(dl);
       prev = out;
@@ -243,6 +250,7 @@ static int build_model(uwm_model* m) {
       char pre[64]; snprintf(pre, sizeof(pre), "decoder.blocks.x_%d_%d", dep, lay);
       blk_in[dep][lay] = cin_; blk_skip[dep][lay] = cskip;
       blk_c1[dep][lay] = add_conv(m, std::string(pre) + ".conv1.0", cin_ + cskip, cout_, 3, 1, 1, 0, true, std::string(pre) + ".conv1.1");
+      m->convs[blk_c1[dep][lay]].c0 = cin_;
       blk_c2[dep][lay] = add_conv(m, std::string(pre) + ".conv2.0", cout_, cout_, 3, 1, 1, 0, true, std::string(pre) + ".conv2.1");
     };
     for (int lay = 0; lay < 4; ++lay)            // registration order of smp's ModuleDict = state_dict order
@@ -333,7 +341,7 @@ static int build_model(uwm_model* m) {
 
 // ------------------------------------------------------------------------------ workspace plan
 static void make_plan(uwm_model* m, int N, int H, int W, int training) {
-  Plan p; p.N = N; p.H = H; p.W = W; p.training = training; p.wino_mode = m->wino_mode;
+  Plan p; p.N = N; p.H = H; p.W = W; p.training = training; p.wino_mode = m->wino_mode; p.prec = m->prec;
   size_t off = m->fixed_floats;
   auto alloc = [&](size_t floats) { size_t o = off; off += (size_t)rup((long long)floats, 64); return o; };
   const size_t nc = m->convs.size();
@@ -502,7 +510,13 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
   a.bytes = 4.0 * ((double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) + (double)cv.Cout * cv.Kpad +
                    (double)a.M * cv.CoutP);
-  if (cv.wu_off && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout); }
+  if (cv.wu_off && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) {
+    a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout);
+    if (c.m->plan.prec == UWM_PREC_BF16X3_ALL && cv.x3()) {
+      if (a.C0 != cv.c0 && a.C0 != a.Ctot) return hipErrorInvalidValue;       // the bank was split for this concat boundary
+      a.prec = 1;
+    }
+  }
   a.wino = c.m->plan.wino_mode + 1;
   return launch_conv(a, c.st, cfg);
 }
@@ -523,7 +537,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
   a.bytes = 4.0 * ((double)c.N * Ho * Wo * cv.CoutP + (double)cv.CinP * cv.KpadD +
                    (double)a.M * cv.CinP * (1.0 + (addend ? 1.0 : 0.0) + (mask ? 1.0 : 0.0)));
-  if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); }
+  if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); if (c.m->plan.prec != UWM_PREC_F32 && cv.x3_d()) a.prec = 1; }
   a.wino = c.m->plan.wino_mode + 1;
   if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
   return launch_conv(a, c.st);
@@ -593,18 +607,26 @@ static hipError_t run_bn_bwd_act(const Ctx& c, int ci, const float* g, float* dy
 // weights), at most 40 layers per launch
 static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
   if (c.m->plan.wino_mode == 0) return hipSuccess;
-  WinoJobs jobs; jobs.n = 0;
   const uwm_model* m = c.m;
-  for (size_t ci = 0; ci < m->convs.size(); ++ci) {
-    const ConvL& cv = m->convs[ci];
-    if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off)) continue;
-    WinoJob& j = jobs.j[jobs.n++];
-    j.w = m->params + cv.w_off; j.Kpad = cv.Kpad; j.pad_ = 0;
-    if (dgrad) { j.ut = c.F(cv.wud_off); j.rows = cv.CinP; j.chans = cv.CoutP; j.mode = 2; j.src_rows = cv.Cout; }
-    else { j.ut = c.F(cv.wu_off); j.rows = cv.Cout; j.chans = cv.CinP; j.mode = 0; j.src_rows = cv.Cout; }
-    if (jobs.n == 40) { hipError_t e = launch_wino_weights_multi(jobs, st); if (e != hipSuccess) return e; jobs.n = 0; }
+  // two passes: fp32 banks, then (bf16x3 precision mode) the split-bf16 banks of the layers that run on conv_wino_x3
+  for (int x3 = 0; x3 <= (m->plan.prec != UWM_PREC_F32 ? 1 : 0); ++x3) {
+    WinoJobs jobs; jobs.n = 0;
+    auto flush = [&]() { hipError_t e = x3 ? launch_wino_weights_x3_multi(jobs, st) : launch_wino_weights_multi(jobs, st); jobs.n = 0; return e; };
+    for (size_t ci = 0; ci < m->convs.size(); ++ci) {
+      const ConvL& cv = m->convs[ci];
+      if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off)) continue;
+      const bool is_x3 = dgrad ? (m->plan.prec != UWM_PREC_F32 && cv.x3_d()) : (m->plan.prec == UWM_PREC_BF16X3_ALL && cv.x3());
+      if (is_x3 != (x3 == 1)) continue;
+      WinoJob& j = jobs.j[jobs.n++];
+      j.w = m->params + cv.w_off; j.Kpad = cv.Kpad; j.pad_ = 0;
+      if (dgrad) { j.ut = c.F(cv.wud_off); j.rows = cv.CinP; j.chans = cv.CoutP; j.mode = 2; j.src_rows = cv.Cout; }
+      else { j.ut = c.F(cv.wu_off); j.rows = cv.Cout; j.chans = cv.CinP; j.mode = 0; j.src_rows = cv.Cout; }
+      if (jobs.n == 40) { hipError_t e = flush(); if (e != hipSuccess) return e; }
+    }
+    hipError_t e = flush();
+    if (e != hipSuccess) return e;
   }
-  return launch_wino_weights_multi(jobs, st);
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -631,7 +653,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     }
     LCHK(wino_jobs(c, true, m->side));
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
-    m->packed_in_fwd = true; m->pack_mode = p.wino_mode;
+    m->packed_in_fwd = true; m->pack_mode = p.wino_mode * 4 + p.prec;
   }
   LCHK(wino_jobs(c, false, st));
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
@@ -804,7 +826,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
     HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
     if (p.se_gs_floats) HIPCHK(hipMemsetAsync(c.F(p.se_gs_all), 0, p.se_gs_floats * sizeof(float), st));
-    if (m->packed_in_fwd && m->pack_mode == p.wino_mode) {      // (a mode switch between forward and backward: redo them)
+    if (m->packed_in_fwd && m->pack_mode == p.wino_mode * 4 + p.prec) {      // (a mode switch between forward and backward: redo them)
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
       m->packed_in_fwd = false;           // joined
     } else {
@@ -1322,7 +1344,7 @@ int uwm_debug_lookup(uwm_handle h, const char* key, long long* off, long long* c
 
 // ---- single-operator entry points
 // Winograd weights for the op-level entry points (tests): transformed into a cached scratch buffer
-static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st) {
+static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st, bool x3 = false) {
   static float* buf = nullptr; static size_t cap = 0;
   const size_t need = wino_weights_floats(a.wrows, a.Ctot);
   if (need > cap) {
@@ -1330,7 +1352,16 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st) {
     if (buf) HIPCHK(hipFree(buf));
     HIPCHK(hipMalloc((void**)&buf, need * sizeof(float))); cap = need;
   }
-  LCHK(launch_wino_weights(a.w, a.wrows, a.Kpad, a.Ctot, mirror, buf, st));
+  if (x3) {           // bf16x3 bank (forward layout only: the model derives dgrad banks from the forward weights itself)
+    if (mirror || (a.Ctot & 15)) return fail("uwm_op_conv: cfg 400 (bf16x3 Winograd) takes forward weights with channels %% 16 == 0");
+    WinoJobs jobs; jobs.n = 1;
+    WinoJob& j = jobs.j[0];
+    j.w = a.w; j.ut = buf; j.rows = a.wrows; j.chans = a.Ctot; j.Kpad = a.Kpad; j.mode = 0; j.src_rows = a.wrows; j.pad_ = 0;
+    LCHK(launch_wino_weights_x3_multi(jobs, st));
+    a.prec = 1;
+  } else {
+    LCHK(launch_wino_weights(a.w, a.wrows, a.Kpad, a.Ctot, mirror, buf, st));
+  }
   a.wu = buf; a.wu_ncb = wino_ncb(a.wrows);
   return 0;
 }
@@ -1371,6 +1402,14 @@ int uwm_set_winograd_mode(uwm_handle h, int mode) {
   return 0;
 }
 int uwm_get_winograd_mode(uwm_handle h) { return h ? h->wino_mode : -1; }
+int uwm_set_precision(uwm_handle h, int mode) {
+  if (!h) return fail("uwm_set_precision: null handle");
+  if (mode != UWM_PREC_F32 && mode != UWM_PREC_BF16X3 && mode != UWM_PREC_BF16X3_ALL)
+    return fail("uwm_set_precision: mode must be UWM_PREC_F32 (0), UWM_PREC_BF16X3 (1) or UWM_PREC_BF16X3_ALL (2), got %d", mode);
+  h->prec = mode; h->plan.prec = mode;          // the workspace layout does not depend on the mode (the banks have one size)
+  return 0;
+}
+int uwm_get_precision(uwm_handle h) { return h ? h->prec : -1; }
 
 // ---- data-parallel exchange on the C ABI: SUM all-reduce of the gradient arena ranges of backward
 // stages [stage_begin, stage_end) over an RCCL communicator, one collective per stage (= bucket), enqueued on `stream`.
@@ -1420,7 +1459,7 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
-    if (op_wino_prepare(a, 0, (hipStream_t)stream)) return 1;
+    if (op_wino_prepare(a, 0, (hipStream_t)stream, cfg == 400)) return 1;
   } else if (cfg >= 300 && cfg < 500) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
   LCHK(launch_conv(a, (hipStream_t)stream, cfg));
   return 0;

@@ -147,6 +147,7 @@ class Unet(nn.Module):
         self._n_mb = lib.uwm_num_mbconv_blocks(h)
         self._mb_drop = [float(lib.uwm_mbconv_drop_rate(h, i)) for i in range(self._n_mb)]
         self.drop_connect = self._n_mb > 0
+        self.precision = "f32"
         self._arena_grads_only = False    # set by the fused flat optimizers: backward() leaves p.grad unset, gradients stay in the arena
         self._keep_override = None        # tests: {0,1} keep masks [n_blocks, N] instead of a random draw
         self._rowscale = None
@@ -218,6 +219,19 @@ class Unet(nn.Module):
 
     def num_parameters(self) -> int:
         return int(L.lib().uwm_param_count(self._h))
+
+    def set_precision(self, mode: str = "f32"):
+        """Arithmetic of the convolution products, per model (uwm_set_precision): "f32" (default: exact fp32 matrix
+        instructions); "bf16x3" (opt-in: the backward data-gradient convolutions take each product as a_hi*b_hi + a_hi*b_lo +
+        a_lo*b_hi over bf16 halves of the fp32 operands, fp32 accumulation — the forward, hence every logit, is unchanged);
+        "bf16x3_all" (forward products too: 1.6e-3 logit error on resnet34, outside the 1e-3 bar on deep encoders).
+        Parameters, activations, gradients and optimizer state stay fp32.  The reference's GPU path is reduced precision
+        as well (fp16 autocast + GradScaler, /root/reference/src/train.py:75,89-98)."""
+        if mode not in L.PREC:
+            raise ValueError(f"unsupported precision {mode!r} (supported: {list(L.PREC)})")
+        L.check(L.lib().uwm_set_precision(self._h, L.PREC[mode]), ValueError)
+        self.precision = mode
+        return self
 
     def conv_flops(self, h: int, w: int):
         """Algorithmic conv FLOPs per image at h x w: (forward, forward+backward) — SURVEY.md 8(d)."""
