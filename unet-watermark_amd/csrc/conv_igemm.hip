@@ -305,6 +305,15 @@ int device_cu_count() {
   return cus[dev];
 }
 
+// mirrors the auto routing below: true when launch_conv(a, st) ends on conv_wino_kernel<NI> / conv_wino_x3_kernel
+bool conv_routes_to_wino(const ConvArgs& a) {
+  if (a.out_up) return a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a);
+  static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
+  if (!no_head && (conv_head_applicable(a) || conv_head_dgrad_applicable(a))) return false;
+  if (!(wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a))) return false;
+  return a.prec == 1 || !conv_wino8_applicable(a);        // (the 8-wave variant has no fused BatchNorm-backward sums)
+}
+
 // tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;

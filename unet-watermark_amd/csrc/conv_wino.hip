@@ -333,6 +333,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = {0.f, 0.f, 0.f, 0.f};
   const int cq = tid % CQ;
   const int co = n0 + cq * 4;
+  // fused BatchNorm-backward sums (a dgrad whose masked output is the gradient wrt a BatchNorm output): second sum = v * yhat
+  const bool bnb = a.bnb_mean != nullptr;
+  const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;      // channels the sums cover
+  f4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = {0.f, 0.f, 0.f, 0.f};
+  if (bnb && co < stat_c) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
 #pragma unroll
   for (int it = 0; it < (ITEMS > 0 ? ITEMS : 1); ++it) {
     const int item = it * 256 + tid;
@@ -352,9 +357,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
           const size_t o2 = (((size_t)n * (a.Ho >> 1) + (ho >> 1)) * (a.Wo >> 1) + (wo >> 1)) * a.up_c0 + co;
           if (a.up_mask) {
             f4 mk = *(const f4*)(a.up_mask + o2);
+            const f4 yr = mk;
             if (a.up_mscale) mk = mk * *(const f4*)(a.up_mscale + co) + *(const f4*)(a.up_mshift + co);
             v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
             v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            if (bnb) { ps_ += v; pq_ += v * ((yr - bmu) * brs); }
           }
           if (a.up_accum) v += *(const f4*)(a.out_up + o2);
           *(f4*)(a.out_up + o2) = v;
@@ -381,14 +388,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
           const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
           if (a.bias) v += *(const f4*)(a.bias + co);
           if (a.addend) v += *(const f4*)(a.addend + o);
+          f4 yr = {0.f, 0.f, 0.f, 0.f};
           if (a.mask) {
             f4 mk = *(const f4*)(a.mask + o);
+            yr = mk;
             if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
             v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
             v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
           }
           *(f4*)(a.out + o) = v;
-          ps_ += v; pq_ += v * v;
+          ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
         }
       }
   }
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
     __syncthreads();
     if (tid < BN) {
       const int c1 = n0 + tid;
-      if (c1 < a.Cout) {
+      if (c1 < stat_c) {
         double sv = 0.0, qv = 0.0;
         for (int g = 0; g < G; ++g) { sv += (double)red[(g * BN + tid) * 2]; qv += (double)red[(g * BN + tid) * 2 + 1]; }
         atomicAdd(a.ssum + srep_off + c1, sv);
@@ -441,11 +450,12 @@ bool conv_wino_applicable(const ConvArgs& a) {
 // bn: 0 auto | 64 | 32 | 16 output channels per workgroup
 hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn) {
   if (!conv_wino_applicable(a)) return hipErrorInvalidValue;
-  if (a.out_up && ((a.Ho | a.Wo) & 1 || (a.up_c0 & 3) || a.up_c0 > a.Cout || a.addend || a.mask || a.bias || a.ssum ||
+  if (a.out_up && ((a.Ho | a.Wo) & 1 || (a.up_c0 & 3) || a.up_c0 > a.Cout || a.addend || a.mask || a.bias || (a.ssum && !a.bnb_mean) ||
                    (a.up_c0 < a.Cout && !a.out) || bn == 8))
     return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : a.mask) || a.up_accum || bn == 8)) return hipErrorInvalidValue;
   if (bn == 8) return launch_conv_wino8(a, st);
-  if (bn <= 0 && conv_wino8_applicable(a)) return launch_conv_wino8(a, st);
+  if (bn <= 0 && !a.bnb_mean && conv_wino8_applicable(a)) return launch_conv_wino8(a, st);
   if (bn <= 0) {
     bn = a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16);
     // deep, spatially small layers: 64-channel tiles leave half the workgroup slots empty -> 32-channel tiles

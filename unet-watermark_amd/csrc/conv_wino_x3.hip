@@ -286,6 +286,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3_kernel(const ConvArgs a) 
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = {0.f, 0.f, 0.f, 0.f};
   const int cq = tid % CQ;
   const int co = n0 + cq * 4;
+  // fused BatchNorm-backward sums, as in conv_wino.hip
+  const bool bnb = a.bnb_mean != nullptr;
+  const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;
+  f4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = {0.f, 0.f, 0.f, 0.f};
+  if (bnb && co < stat_c) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
   {
     const int t = tid / CQ;
     f4 q[4][2];
@@ -302,9 +307,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3_kernel(const ConvArgs a) 
           const size_t o2 = (((size_t)n * (a.Ho >> 1) + (ho >> 1)) * (a.Wo >> 1) + (wo >> 1)) * a.up_c0 + co;
           if (a.up_mask) {
             f4 mk = *(const f4*)(a.up_mask + o2);
+            const f4 yr = mk;
             if (a.up_mscale) mk = mk * *(const f4*)(a.up_mscale + co) + *(const f4*)(a.up_mshift + co);
             v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
             v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            if (bnb) { ps_ += v; pq_ += v * ((yr - bmu) * brs); }
           }
           if (a.up_accum) v += *(const f4*)(a.out_up + o2);
           *(f4*)(a.out_up + o2) = v;
@@ -330,19 +337,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3_kernel(const ConvArgs a) 
             const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
             if (a.bias) v += *(const f4*)(a.bias + co);
             if (a.addend) v += *(const f4*)(a.addend + o);
+            f4 yr = {0.f, 0.f, 0.f, 0.f};
             if (a.mask) {
               f4 mk = *(const f4*)(a.mask + o);
+              yr = mk;
               if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
               v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
               v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
             }
             *(f4*)(a.out + o) = v;
-            ps_ += v; pq_ += v * v;
+            ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
           }
         }
     }
   }
-  if (do_stats && a.out_up == nullptr) {
+  if (do_stats) {
     __syncthreads();                       // Q is dead
     float* red = smem;                     // [32 groups][BN][2]
     constexpr int G = 256 / CQ;
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_x3_kernel(const ConvArgs a) 
     __syncthreads();
     if (tid < BN) {
       const int c1 = n0 + tid;
-      if (c1 < a.Cout) {
+      if (c1 < stat_c) {
         double sv = 0.0, qv = 0.0;
         for (int g = 0; g < G; ++g) { sv += (double)red[(g * BN + tid) * 2]; qv += (double)red[(g * BN + tid) * 2 + 1]; }
         atomicAdd(a.ssum + srep_off + c1, sv);
@@ -372,9 +381,10 @@ bool conv_wino_x3_applicable(const ConvArgs& a) {
 
 hipError_t launch_conv_wino_x3(const ConvArgs& a, hipStream_t st) {
   if (!conv_wino_x3_applicable(a)) return hipErrorInvalidValue;
-  if (a.out_up && ((a.Ho | a.Wo) & 1 || (a.up_c0 & 3) || a.up_c0 > a.Cout || a.addend || a.mask || a.bias || a.ssum ||
+  if (a.out_up && ((a.Ho | a.Wo) & 1 || (a.up_c0 & 3) || a.up_c0 > a.Cout || a.addend || a.mask || a.bias || (a.ssum && !a.bnb_mean) ||
                    (a.up_c0 < a.Cout && !a.out)))
     return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : a.mask) || a.up_accum)) return hipErrorInvalidValue;
   const int tilesN = (a.Cout + kBN - 1) / kBN;
   const int tilesW = (a.Wo + kTW - 1) / kTW, tilesH = (a.Ho + kTH - 1) / kTH;
   const size_t main_lds = (size_t)(2 * kUs + 4 * kPlane) * sizeof(float);

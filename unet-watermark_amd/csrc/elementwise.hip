@@ -255,6 +255,18 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
   return hipGetLastError();
 }
 
+__global__ void bn_bwd_fold_kernel(const double* __restrict__ rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sb = 0.0, sg = 0.0;
+  for (int r = 0; r < nrep; ++r) { sb += rep[(size_t)r * rep_stride + c]; sg += rep[(size_t)r * rep_stride + C + c]; }
+  dbeta[c] = sb; dgamma[c] = sg;
+}
+hipError_t launch_bn_bwd_fold(const double* rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, rep, nrep, rep_stride, C, dgamma, dbeta);
+  return hipGetLastError();
+}
+
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const double* __restrict__ dgamma, const double* __restrict__ dbeta, float* __restrict__ dy,

@@ -58,6 +58,11 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   const float* mscale; const float* mshift;
   double* ssum; double* ssq; // per-channel sum / sum of squares of the output, or nullptr
   int srep, sstride;         // statistics replicas: workgroup b adds into copy (b & (srep-1)) at +copy*sstride doubles (srep: power of 2, 0/1 = none)
+  // BatchNorm-backward sums fused into a dgrad epilogue (conv_wino.hip / conv_wino_x3.hip only; bnb_mean != nullptr): the
+  // epilogue's masked output v IS the gradient wrt a BatchNorm output whose raw input it has just read as the ReLU mask
+  // (`mask` / `up_mask`), so it accumulates ssum += v (dbeta) and ssq += v * (mask_raw - mean) * rstd (dgamma) instead of the
+  // forward's (v, v^2): bn_bwd_reduce's pass over both tensors disappears
+  const float* bnb_mean; const float* bnb_rstd;
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
   double bytes;              // algorithmic HBM bytes of this launch: every operand read once + the output written once (profiling only)
@@ -116,6 +121,7 @@ const char* prof_class_name(int cls);
 
 // ---- launchers (all asynchronous on `st`, no host sync, no allocation) ----
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg = -1);
+bool conv_routes_to_wino(const ConvArgs& a);      // launch_conv (auto routing) will run this launch on conv_wino / conv_wino_x3 (the epilogues that can carry bnb_*)
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st);
 // 3x3 s1 p1 patch-tiled conv (conv_patch.hip); launch_conv routes to it when applicable.
 // force_cfg for launch_conv: -1 auto, 0..5 conv_igemm tile config, 100+BN (116,132,164,228) conv_patch, 200 conv_patch16
@@ -175,6 +181,8 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
 hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd,
                                const float* gamma, const double* dgamma, const double* dbeta, float* dy,
                                float* gamma_grad, float* beta_grad, size_t npix, int C, hipStream_t st);
+// dgamma[c] / dbeta[c] = sum over the nrep replicas {dbeta part[C], dgamma part[C]} a fused dgrad epilogue filled
+hipError_t launch_bn_bwd_fold(const double* rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta, hipStream_t st);
 // dcat [N][H][W][C0+C1] -> gprev [N][H/2][W/2][C0] = mask(sum 2x2), gskip [N][H][W][C1] (copy)
 hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev,
                           const float* pmask, const float* pscale, const float* pshift, float* gskip,

@@ -523,9 +523,13 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
 
 struct UpSplit { float* gprev; int C0; const float* pmask; const float* pscale; const float* pshift; int accumulate = 0; };
 // dX = dgrad(dY) (+addend) (*mask); with `us`: decoder concat split fused into the epilogue (dx = gskip or nullptr)
+// bn_fuse >= 0: the masked output of this dgrad is the gradient wrt the output of BatchNorm `bn_fuse`, whose raw input is the
+// ReLU mask the epilogue reads anyway: where the launch runs on a Winograd epilogue the BatchNorm-backward sums (dbeta,
+// dgamma partials, one of nrep replicas per workgroup) are accumulated there and *fused = true tells run_bn_bwd to skip
+// its reduce pass
 static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int Wo, int Hin, int Win, float* dx,
                             const float* addend, const float* mask, const float* mscale, const float* mshift,
-                            const UpSplit* us = nullptr) {
+                            const UpSplit* us = nullptr, int bn_fuse = -1, bool* fused = nullptr) {
   const ConvL& cv = c.m->convs[ci];
   ConvArgs a; memset(&a, 0, sizeof(a));
   a.s0 = mk_src(dy, cv.CoutP, Ho, Wo); a.s1 = a.s0; a.C0 = cv.CoutP; a.Ctot = cv.CoutP;
@@ -540,6 +544,17 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); if (c.m->plan.prec != UWM_PREC_F32 && cv.x3_d()) a.prec = 1; }
   a.wino = c.m->plan.wino_mode + 1;
   if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
+  if (fused) *fused = false;
+  static const bool no_fuse = getenv("UWM_NO_BN_FUSE") != nullptr;
+  if (bn_fuse >= 0 && fused && !no_fuse && (us ? (us->pmask != nullptr && !us->accumulate) : (mask != nullptr)) && conv_routes_to_wino(a)) {
+    const BNL& b = c.m->bns[bn_fuse];
+    if (b.C == (us ? us->C0 : cv.CinP)) {
+      const float* f = c.F(b.f_off);
+      a.bnb_mean = f; a.bnb_rstd = f + b.C;
+      a.ssum = c.D(b.d_off) + 2 * b.C; a.ssq = a.ssum + b.C; a.srep = b.nrep; a.sstride = 2 * b.C;     // the forward's (dead, re-zeroed) replicas
+      *fused = true;
+    }
+  }
   return launch_conv(a, c.st);
 }
 
@@ -581,11 +596,13 @@ static hipError_t run_bn_finalize(const Ctx& c, int bi, size_t count, int traini
 }
 
 // g (masked grad wrt BN output) -> dy ; also writes gamma/beta gradients
-static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, size_t npix) {
+static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, size_t npix, bool sums_fused = false) {
   uwm_model* m = c.m; const ConvL& cv = m->convs[ci]; const BNL& b = m->bns[cv.bn];
   const float* f = c.F(b.f_off); const float* y = c.F(m->plan.y[ci]);
   double* dg = c.D(b.d_off); double* db = c.D(b.d_off) + b.C;
-  hipError_t e = launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
+  // sums_fused: the dgrad that produced g left per-workgroup-replica partial sums behind (run_dgrad bn_fuse): add the replicas
+  hipError_t e = sums_fused ? launch_bn_bwd_fold(c.D(b.d_off) + 2 * b.C, b.nrep, 2 * b.C, b.C, dg, db, c.st)
+                            : launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
   if (e != hipSuccess) return e;
   return launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, dg, db, dy, m->grads + b.g_off, m->grads + b.b_off,
                              npix, b.C, c.st);
@@ -848,14 +865,18 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[last_c2]), nullptr, d4.ptr, d4.scale, d4.shift));
     // ---------------- decoder blocks, last to first
     int h = H, w = W;
+    bool c2_sums = false;                                  // BatchNorm-backward sums of dl.c2 already made by the dgrad that wrote its gradient
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
       const DecL& dl = m->dec[i];
       const size_t npix = (size_t)N * h * w;
-      LCHK(run_bn_bwd(c, dl.c2, c.F(p.g[dl.c2]), c.F(p.g[dl.c2]), npix));
+      LCHK(run_bn_bwd(c, dl.c2, c.F(p.g[dl.c2]), c.F(p.g[dl.c2]), npix, c2_sums));
+      c2_sums = false;
       Src a1 = lazy_src(c, dl.c1, h, w);
       LCHK(run_wgrad(c, dl.c2, a1, nullptr, c.F(p.g[dl.c2]), h, w));
-      LCHK(run_dgrad(c, dl.c2, c.F(p.g[dl.c2]), h, w, h, w, c.F(p.g[dl.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
-      LCHK(run_bn_bwd(c, dl.c1, c.F(p.g[dl.c1]), c.F(p.g[dl.c1]), npix));
+      bool c1_sums = false;
+      LCHK(run_dgrad(c, dl.c2, c.F(p.g[dl.c2]), h, w, h, w, c.F(p.g[dl.c1]), nullptr, a1.ptr, a1.scale, a1.shift, nullptr,
+                     m->convs[dl.c1].bn, &c1_sums));
+      LCHK(run_bn_bwd(c, dl.c1, c.F(p.g[dl.c1]), c.F(p.g[dl.c1]), npix, c1_sums));
       // the block's input: cat(up(prev), skip)
       Src prev = (i == 0) ? feat_src(3) : lazy_src(c, m->dec[i - 1].c2, h / 2, w / 2);
       prev.up = 1;
@@ -869,8 +890,9 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
         // Winograd dgrad writes the 2x2-pooled, ReLU-masked gradient of up(prev) and the skip gradient directly:
         // the full-resolution dcat buffer and the upsplit pass never exist
         UpSplit us{gprev, dl.C0, pm, prev.scale, prev.shift, 0};
+        // i > 0: gprev is the gradient wrt relu(bn(conv2 of block i-1)), masked by that conv's raw output: its BN sums ride along
         LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, dl.C1 > 0 ? c.F(p.gskip[i]) : nullptr, nullptr, nullptr, nullptr,
-                       nullptr, &us));
+                       nullptr, &us, i > 0 ? m->convs[m->dec[i - 1].c2].bn : -1, &c2_sums));
       } else {
         LCHK(run_dgrad(c, dl.c1, c.F(p.g[dl.c1]), h, w, h, w, c.F(p.dcat[i]), nullptr, nullptr, nullptr, nullptr));
         LCHK(launch_upsplit(c.F(p.dcat[i]), N, h, w, dl.C0, dl.C1, gprev, pm, prev.scale, prev.shift,
@@ -903,8 +925,10 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
         LCHK(run_bn_bwd(c, nd.c2, c.F(p.g[nd.c2]), c.F(p.g[nd.c2]), npix));
         Src a1 = lazy_src(c, nd.c1, nh, nw);
         LCHK(run_wgrad(c, nd.c2, a1, nullptr, c.F(p.g[nd.c2]), nh, nw));
-        LCHK(run_dgrad(c, nd.c2, c.F(p.g[nd.c2]), nh, nw, nh, nw, c.F(p.g[nd.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
-        LCHK(run_bn_bwd(c, nd.c1, c.F(p.g[nd.c1]), c.F(p.g[nd.c1]), npix));
+        bool c1_sums = false;
+        LCHK(run_dgrad(c, nd.c2, c.F(p.g[nd.c2]), nh, nw, nh, nw, c.F(p.g[nd.c1]), nullptr, a1.ptr, a1.scale, a1.shift, nullptr,
+                       m->convs[nd.c1].bn, &c1_sums));
+        LCHK(run_bn_bwd(c, nd.c1, c.F(p.g[nd.c1]), c.F(p.g[nd.c1]), npix, c1_sums));
         Src prev = tensor_src(nd.prev); prev.up = 1;
         Src skip; const Src* sp = nullptr;
         if (nd.skips.size() == 1) { skip = tensor_src(nd.skips[0]); sp = &skip; }
@@ -1017,8 +1041,10 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       }
       Src a1 = lazy_src(c, bl.c1, hc1, wc1);
       LCHK(run_wgrad(c, bl.c2, a1, nullptr, c.F(p.g[bl.c2]), h, w));
-      LCHK(run_dgrad(c, bl.c2, c.F(p.g[bl.c2]), h, w, hc1, wc1, c.F(p.g[bl.c1]), nullptr, a1.ptr, a1.scale, a1.shift));
-      LCHK(run_bn_bwd(c, bl.c1, c.F(p.g[bl.c1]), c.F(p.g[bl.c1]), (size_t)N * hc1 * wc1));
+      bool c1_sums = false;
+      LCHK(run_dgrad(c, bl.c2, c.F(p.g[bl.c2]), h, w, hc1, wc1, c.F(p.g[bl.c1]), nullptr, a1.ptr, a1.scale, a1.shift, nullptr,
+                     m->convs[bl.c1].bn, &c1_sums));
+      LCHK(run_bn_bwd(c, bl.c1, c.F(p.g[bl.c1]), c.F(p.g[bl.c1]), (size_t)N * hc1 * wc1, c1_sums));
       // block input
       Src in; float* gin; const float* in_mask;
       if (b > 0) { in = mk_src(c.F(p.xn[bi - 1]), bl.Cin, hin, win); gin = c.F(p.gx[bi - 1]); in_mask = in.ptr; }
