@@ -323,6 +323,41 @@ def _dgrad_and_wgrad(cuda, shape, force_igemm):
     assert (dw[:, k * k * rup(cin, 4):] == 0).all()
 
 
+@pytest.mark.parametrize("cout,n,h,w", [(16, 2, 16, 64), (16, 3, 40, 32), (1, 2, 16, 64), (3, 2, 24, 96), (16, 4, 128, 128)])
+def test_wgrad_c16_and_head(cuda, cout, n, h, w):
+    """wgrad_c16.hip: the weight gradient of the 16-channel full-resolution layers (16 -> 16: pixels as the MFMA reduction,
+    9 accumulators) and of the segmentation head (16 -> 1 | 3 classes: taps as the MFMA N dimension), lazily normalised
+    + ReLU-ed input, many tiles per workgroup (128x128 x 4 images), image borders; deterministic: two runs are bit-identical;
+    dW is accumulated (+=) and its padded K columns stay zero."""
+    L = lib()
+    g = torch.Generator().manual_seed(11 + cout)
+    cin = 16
+    xr = torch.randn(n, cin, h, w, generator=g)
+    sc = torch.rand(cin, generator=g) + 0.5; sc[::5] *= -1
+    sh = torch.randn(cin, generator=g) * 0.3
+    x = torch.relu(xr * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(x, wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    coutp = rup(cout, 4)
+    kpad = rup(9 * cin, 32)
+    xd, dyd = nhwc(xr).to(cuda), nhwc(dy).to(cuda)
+    scd, shd = sc.to(cuda), sh.to(cuda)
+    s0 = src(xd, scd, shd, relu=1)
+    runs = []
+    for _ in range(2):
+        dw = torch.full((cout, kpad), 0.25, device=cuda); dw[:, 9 * cin:] = 0
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h, w, coutp, cout, kpad, 3, 3, 1, 1, P(dw), 0, stream()))
+        torch.cuda.synchronize()
+        runs.append(dw.clone())
+    assert torch.equal(runs[0], runs[1])                       # no atomics
+    got = unpack_w(runs[0].cpu(), cout, cin, 3, 3) - 0.25
+    ref = wt.grad
+    assert (got - ref).abs().max() < 3e-5 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+    assert (runs[0][:, 9 * cin:] == 0).all()
+
+
 @pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 32, 32), (32, 32, 64)])
 def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
     L = lib()

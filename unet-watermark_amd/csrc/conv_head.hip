@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) 
   const int nbands = (H + TH - 1) / TH;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   const int pix = idx / CQ, q = idx - pix * CQ;
-  if (pix >= nbands * W) return;
-  const int band = pix / W, wo = pix - band * W;
+  const bool live = pix < nbands * W;             // (no early return: the fused BatchNorm-backward sums end in a workgroup barrier)
+  const int band = live ? pix / W : 0, wo = live ? pix - band * W : 0;
   const int n = blockIdx.y, ho0 = band * TH;
   f4 acc[TH];
 #pragma unroll
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) 
 #pragma unroll
   for (int rr = 0; rr < TH + 2; ++rr) {
     const int hh = ho0 - 1 + rr;
-    if (hh < 0 || hh >= H) continue;
+    if (hh < 0 || hh >= H || !live) continue;
 #pragma unroll
     for (int s2 = 0; s2 < 3; ++s2) {
       const int ww = wo - 1 + s2;
@@ -142,26 +142,47 @@ __global__ __launch_bounds__(256) void conv_head_dgrad_kernel(const ConvArgs a) 
       }
     }
   }
+  // fused BatchNorm-backward sums (uwm_kernels.h ConvArgs::bnb_*): the masked output IS the gradient wrt the BatchNorm output
+  // whose raw input is the mask tensor: dbeta += v, dgamma += v * yhat, per workgroup -> one of srep fp64 replicas
+  const bool bnb = a.bnb_mean != nullptr;
+  f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = {0.f, 0.f, 0.f, 0.f}, bmu = ps_, brs = ps_;
+  if (bnb) { bmu = *(const f4*)(a.bnb_mean + q * 4); brs = *(const f4*)(a.bnb_rstd + q * 4); }
 #pragma unroll
   for (int j = 0; j < TH; ++j) {
     const int ho = ho0 + j;
-    if (ho >= H) continue;
+    if (ho >= H || !live) continue;
     const size_t o = (((size_t)n * H + ho) * W + wo) * C + q * 4;
     f4 v = acc[j];
     if (a.addend) v += *(const f4*)(a.addend + o);
     if (a.mask) {
       f4 mk = *(const f4*)(a.mask + o);
+      const f4 yr = mk;
       if (a.mscale) mk = mk * *(const f4*)(a.mscale + q * 4) + *(const f4*)(a.mshift + q * 4);
       v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      if (bnb) { ps_ += v; pq_ += v * ((yr - bmu) * brs); }
     }
     *(f4*)(a.out + o) = v;
+  }
+  if (bnb) {              // threads = (pixel column, channel quad q = idx % CQ): sum the 256 / CQ columns of a quad through LDS
+    __shared__ float red[256 * 8];
+    float* r = red + threadIdx.x * 8;
+    r[0] = ps_.x; r[1] = ps_.y; r[2] = ps_.z; r[3] = ps_.w; r[4] = pq_.x; r[5] = pq_.y; r[6] = pq_.z; r[7] = pq_.w;
+    __syncthreads();
+    if (threadIdx.x < CQ * 8) {
+      const int qq = threadIdx.x / 8, e = threadIdx.x % 8;
+      // thread t holds quad (blockIdx.x * 256 + t) % CQ = (t + base) % CQ with base = (blockIdx.x * 256) % CQ = 0 (256 % CQ == 0)
+      double sacc = 0.0;
+      for (int k = qq; k < 256; k += CQ) sacc += (double)red[k * 8 + e];
+      const size_t srep_off = a.srep > 1 ? (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (unsigned)(a.srep - 1)) * a.sstride : 0;
+      if (e < 4) atomicAdd(a.ssum + srep_off + qq * 4 + e, sacc); else atomicAdd(a.ssq + srep_off + qq * 4 + (e - 4), sacc);
+    }
   }
 }
 
 bool conv_head_dgrad_applicable(const ConvArgs& a) {
   return a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && a.rmul == -1 && a.off == 1 && a.Ctot == 4 && a.C0 == 4 && a.s0.C == 4 &&
          (a.Cout == 8 || a.Cout == 16 || a.Cout == 32) && a.wrows == a.Cout && a.s0.up == 0 && !a.s0.scale && a.Ho == a.Hl && a.Wo == a.Wl &&
-         !a.ssum && !a.bias && !a.out_up;
+         (!a.ssum || a.bnb_mean) && !a.bias && !a.out_up;
 }
 template <int CQ>
 static hipError_t launch_head_dgrad(const ConvArgs& a, hipStream_t st) {
@@ -173,6 +194,7 @@ static hipError_t launch_head_dgrad(const ConvArgs& a, hipStream_t st) {
 }
 hipError_t launch_conv_head_dgrad(const ConvArgs& a, hipStream_t st) {
   if (!conv_head_dgrad_applicable(a)) return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !a.mask)) return hipErrorInvalidValue;
   switch (a.Cout) {
     case 8: return launch_head_dgrad<2>(a, st);
     case 16: return launch_head_dgrad<4>(a, st);

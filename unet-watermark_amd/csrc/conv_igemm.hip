@@ -305,13 +305,16 @@ int device_cu_count() {
   return cus[dev];
 }
 
-// mirrors the auto routing below: true when launch_conv(a, st) ends on conv_wino_kernel<NI> / conv_wino_x3_kernel
+// mirrors the auto routing below: true when launch_conv(a, st) ends on a kernel whose epilogue can carry the fused
+// BatchNorm-backward sums (ConvArgs::bnb_*): conv_wino_kernel<NI>, conv_wino_x3_kernel, conv_patch16_kernel, conv_head_dgrad_kernel
 bool conv_routes_to_wino(const ConvArgs& a) {
   if (a.out_up) return a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a);
   static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
-  if (!no_head && (conv_head_applicable(a) || conv_head_dgrad_applicable(a))) return false;
-  if (!(wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a))) return false;
-  return a.prec == 1 || !conv_wino8_applicable(a);        // (the 8-wave variant has no fused BatchNorm-backward sums)
+  if (!no_head && conv_head_applicable(a)) return false;
+  if (!no_head && conv_head_dgrad_applicable(a)) return true;
+  if (wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a))
+    return a.prec == 1 || !conv_wino8_applicable(a);      // (the 8-wave variant has no fused BatchNorm-backward sums)
+  return conv_patch16_applicable(a);
 }
 
 // tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}

@@ -102,6 +102,15 @@ __global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
   f4 ps_[NI], pq_[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) { ps_[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq_[j] = ps_[j]; }
+  // fused BatchNorm-backward sums (uwm_kernels.h ConvArgs::bnb_*): second sum = v * yhat of the mask tensor
+  const bool bnb = a.bnb_mean != nullptr;
+  f4 bmu[NI], brs[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + j * 16 + lq * 4;
+    bmu[j] = brs[j] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (bnb && co < a.Cout) { bmu[j] = *(const f4*)(a.bnb_mean + co); brs[j] = *(const f4*)(a.bnb_rstd + co); }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int ho = h0 + wm * MI + i, wo = w0 + lrow;
@@ -115,14 +124,16 @@ __global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
         const size_t o = m * a.Cout + co;
         if (a.bias) v += *(const f4*)(a.bias + co);
         if (a.addend) v += *(const f4*)(a.addend + o);
+        f4 yr = {0.f, 0.f, 0.f, 0.f};
         if (a.mask) {
           f4 mk = *(const f4*)(a.mask + o);
+          yr = mk;
           if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
           v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
           v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
         }
         *(f4*)(a.out + o) = v;
-        ps_[j] += v; pq_[j] += v * v;
+        ps_[j] += v; pq_[j] += bnb ? v * ((yr - bmu[j]) * brs[j]) : v * v;
       }
     }
   }
@@ -179,6 +190,7 @@ bool conv_patch16_applicable(const ConvArgs& a) {
 
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st) {
   if (!conv_patch16_applicable(a) || (a.Cout & 3)) return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !a.mask)) return hipErrorInvalidValue;
   return a.Cout > 16 ? launch_p16<32>(a, st, 18) : launch_p16<16>(a, st, 17);
 }
 

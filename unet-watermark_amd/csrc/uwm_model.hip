@@ -862,10 +862,12 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     Src d4 = lazy_src(c, last_c2, H, W);
     LCHK(run_wgrad(c, m->head, d4, nullptr, dlogits, H, W));
     LCHK(launch_colsum(dlogits, (size_t)N * H * W, hd.CoutP, m->grads + hd.bias_off, nullptr, st));
-    LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[last_c2]), nullptr, d4.ptr, d4.scale, d4.shift));
+    bool head_sums = false;                               // BatchNorm-backward sums of the last decoder conv, made by the head's dgrad
+    LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[last_c2]), nullptr, d4.ptr, d4.scale, d4.shift, nullptr,
+                   m->convs[last_c2].bn, &head_sums));
     // ---------------- decoder blocks, last to first
     int h = H, w = W;
-    bool c2_sums = false;                                  // BatchNorm-backward sums of dl.c2 already made by the dgrad that wrote its gradient
+    bool c2_sums = head_sums;                              // BatchNorm-backward sums of dl.c2 already made by the dgrad that wrote its gradient
     for (int i = (int)m->dec.size() - 1; i >= 0; --i) {
       const DecL& dl = m->dec[i];
       const size_t npix = (size_t)N * h * w;
@@ -922,7 +924,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
         const int nh = H >> nd.lvl, nw = W >> nd.lvl;
         const size_t npix = (size_t)N * nh * nw;
         if (!ginit[5 + i]) return fail("internal: UnetPlusPlus node %d has no consumer", i);
-        LCHK(run_bn_bwd(c, nd.c2, c.F(p.g[nd.c2]), c.F(p.g[nd.c2]), npix));
+        LCHK(run_bn_bwd(c, nd.c2, c.F(p.g[nd.c2]), c.F(p.g[nd.c2]), npix, i == (int)m->nodes.size() - 1 && head_sums));
         Src a1 = lazy_src(c, nd.c1, nh, nw);
         LCHK(run_wgrad(c, nd.c2, a1, nullptr, c.F(p.g[nd.c2]), nh, nw));
         bool c1_sums = false;

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 constexpr int kMaxPartBlocks = 1024;          // workgroups of a split launch: bounds the partial-sum scratch
 size_t wgrad_wino_scratch_floats() { return (size_t)kMaxPartBlocks * 64 * kCW * 9; }
 
-static float* op_scratch() {                  // single-operator entry points (no workspace): one cached buffer per device
+float* wgrad_op_scratch() {                   // single-operator entry points (no workspace): one cached buffer per device
   static float* buf[64] = {nullptr};
   int dev = 0; (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) return nullptr;
@@ -606,7 +606,7 @@ hipError_t launch_wgrad_wino(const WgradArgs& a0, hipStream_t st) {
   if (nsplit < 8) nsplit = (nstages + tps - 1) / tps;               // (a multiple of 8 keeps its empty tail splits: t0 >= t1)
   a.nsplit = nsplit; a.msplit = tps;
   if (nsplit > 1) {
-    if (!a.part || a.part_floats < (size_t)nsplit * a.wrows * a.Kpad) { a.part = op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); }
+    if (!a.part || a.part_floats < (size_t)nsplit * a.wrows * a.Kpad) { a.part = wgrad_op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); }
     if (!a.part || a.part_floats < (size_t)nsplit * a.wrows * a.Kpad) return hipErrorOutOfMemory;
   }
   const int nblocks = nsplit * tilesA * nchunk;
