@@ -806,7 +806,7 @@ def test_cli_train_efficientnet_b4_checkpoint_and_predictor(cuda, tmp_path):
     drop-connect, running statistics) reproduces the eager forward bit for bit."""
     from unet_watermark_amd import cli
     hist = cli.main(["train", "--epochs", "3", "--batch-size", "4", "--lr", "0.002", "--no-early-stopping",
-                     "--synthetic", "32", "--img-size", "64", "--encoder", "efficientnet-b4", "--workers", "0",
+                     "--synthetic", "32", "--img-size", "64", "--encoder", "efficientnet-b4", "--workers", "0", "--model", "Unet",
                      "--model-save-path", str(tmp_path / "eff.pth")])
     assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
     from unet_watermark_amd.checkpoint import load_checkpoint
