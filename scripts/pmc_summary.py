@@ -21,7 +21,7 @@ dur = collections.defaultdict(float); cnt = collections.Counter()
 for r in csv.DictReader(open(tr)):
     k = norm(r["Kernel_Name"]); dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[k] += 1
 rows, traffic = [], {}
-alias = {"wgrad_patch_kernel<64,32>": "wgrad_patch_kernel<64>", "wgrad_patch_kernel<32,32>": "wgrad_patch_kernel<32>",
+alias = {"wgrad_patch_kernel<64,32>": "wgrad_patch_kernel<64>", "conv_wino_x3_kernel": "conv_wino_x3_kernel", "wgrad_patch_kernel<32,32>": "wgrad_patch_kernel<32>",
          "wgrad_patch_kernel<16,32>": "wgrad_patch_kernel<16>",
          # template parameter is channel tiles of 16; the profiler class names say channels
          "conv_wino_kernel<4>": "conv_wino_kernel<64>", "conv_wino_kernel<2>": "conv_wino_kernel<32>",

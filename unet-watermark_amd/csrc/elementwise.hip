@@ -646,7 +646,7 @@ const char* prof_class_name(int cls) {
       "conv_patch_kernel<32,4,1>",      "conv_patch_kernel<16,4,1>",      "wgrad_patch_kernel<16>",
       "wgrad_patch_kernel<32>",         "wgrad_patch_kernel<64>",         "conv_patch16_kernel<16>",
       "conv_patch16_kernel<32>",        "conv_wino_kernel<64>",           "conv_wino_kernel<32>",
-      "conv_wino_kernel<16>",           "wgrad_wino_kernel<64>",          "wgrad_wino_kernel<32>",
+      "conv_wino_kernel<16>",           "wgrad_wino2_kernel<64>",         "wgrad_wino2_kernel<32>",
       "wgrad_wino_kernel<16>",          "conv_wino8_kernel",              "wgrad_igemm_kernel<128,32,2,2>",
       "wgrad_igemm_kernel<128,64,2,2>",  "wgrad_igemm_kernel<32,64,2,2>",  "wgrad_igemm_kernel<32,128,1,4>",
       "conv_head_kernel",               "conv_wino_x3_kernel",            "wgrad_c16_kernel",

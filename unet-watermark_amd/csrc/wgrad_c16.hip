@@ -189,16 +189,24 @@ __global__ __launch_bounds__(256, 3) void wgrad_head_kernel(const WgradArgs a, c
   }
 }
 
-// dw[i] += part[0][i] + part[1][i] + ... in workgroup order; one workgroup per 64 elements, 4 partial-ranges per element
-// summed by 4 thread groups, then combined in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void wgrad_c16_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ dw) {
-  __shared__ float red[4][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-  float s = 0.f;
-  if (e < n) for (int k = grp; k < nparts; k += 4) s += part[(size_t)k * n + e];
-  red[grp][threadIdx.x & 63] = s;
+// dw[i] += part[0][i] + part[1][i] + ... (16-byte units).  Workgroup = 8 units x 32 partial groups: thread (unit, group) adds
+// partials group, group + 32, ... in order, the 32 group sums are combined in group order through LDS (fixed association:
+// bit-reproducible); hundreds of partial tiles of only 10 KB each, so the parallelism has to come from the partial index
+__global__ __launch_bounds__(256) void wgrad_c16_reduce_kernel(const float* __restrict__ part, int nparts, int n4, float* __restrict__ dw) {
+  __shared__ f4 red[32][8];
+  const int u = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + u;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int k = grp; k < nparts; k += 32) s += *(const f4*)(part + ((size_t)k * n4 + i) * 4);
+  red[grp][u] = s;
   __syncthreads();
-  if (grp == 0 && e < n) dw[e] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (grp == 0 && i < n4) {
+    f4 t = red[0][u];
+#pragma unroll
+    for (int g = 1; g < 32; ++g) t += red[g][u];
+    *(f4*)(dw + i * 4) += t;
+  }
 }
 
 bool wgrad_c16_applicable(const WgradArgs& a) {
@@ -224,8 +232,8 @@ hipError_t launch_wgrad_c16(const WgradArgs& a0, hipStream_t st) {
   } else {
     UWM_LAUNCH(33, a.flops, a.bytes, (wgrad_head_kernel<4>), dim3((unsigned)nwg), dim3(256), lds, st, a, g);
   }
-  const int n = a.wrows * a.Kpad;
-  hipLaunchKernelGGL(wgrad_c16_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, (const float*)a.part, nwg, n, a.dw);
+  const int n4 = a.wrows * a.Kpad / 4;
+  hipLaunchKernelGGL(wgrad_c16_reduce_kernel, dim3((unsigned)((n4 + 7) / 8)), dim3(256), 0, st, (const float*)a.part, nwg, n4, a.dw);
   return hipGetLastError();
 }
 

@@ -524,12 +524,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(const WgradArgs a) 
   }
 }
 
-// dw[i] += part[0][i] + part[1][i] + ... in split order (16-byte units); n4 = wrows * Kpad / 4
+// dw[i] += part[0][i] + part[1][i] + ... (16-byte units; n4 = wrows * Kpad / 4).  Workgroup = 32 units x 8 split groups:
+// thread (unit, group) adds splits group, group + 8, ... in order, the 8 group sums are combined in group order through
+// LDS — a fixed association for a given nsplit, so the result is bit-reproducible; the first version walked all splits
+// serially per thread (36 workgroups of 256 dependent loads on a 64x64 layer: 35-80 us per launch, 1.35 ms per step).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n4, float* __restrict__ dw) {
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    f4 s = *(const f4*)(part + i * 4);
-    for (int k = 1; k < nsplit; ++k) s += *(const f4*)(part + ((size_t)k * n4 + i) * 4);
-    *(f4*)(dw + i * 4) += s;
+  __shared__ f4 red[8][32];
+  const int u = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + u;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int k = grp; k < nsplit; k += 8) s += *(const f4*)(part + ((size_t)k * n4 + i) * 4);
+  red[grp][u] = s;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    f4 t = red[0][u];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][u];
+    *(f4*)(dw + i * 4) += t;
   }
 }
 
@@ -561,8 +573,7 @@ static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nbl
   }
   if (a.nsplit > 1) {
     const size_t n4 = (size_t)a.wrows * a.Kpad / 4;
-    unsigned nb = (unsigned)((n4 + 255) / 256); if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)a.part, a.nsplit, n4, a.dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float*)a.part, a.nsplit, n4, a.dw);
   }
   return hipGetLastError();
 }
