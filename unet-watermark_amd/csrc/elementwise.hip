@@ -42,14 +42,27 @@ hipError_t launch_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, i
 }
 
 // ------------------------------------------------------------------ BatchNorm finalize
-__global__ void bn_finalize_kernel(const double* ssum, const double* ssq, const float* gamma, const float* beta,
+// 46 launches per resnet34 step sit on the main stream's critical path and each has almost nothing to do: what matters is
+// the length of the dependent-load chain.  A workgroup = 16 channels x 16 replica lanes: lane r adds replicas r, r+16, ...
+// (independent loads, all in flight at once), the 16 partials are combined by a fixed xor tree (bit-reproducible), lane 0
+// of each channel finishes.  (One thread per channel walking 32 replicas measured 7.3 us per launch.)
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ssum, const double* __restrict__ ssq, const float* gamma, const float* beta,
                                    float* run_mean, float* run_var, float* mean, float* rstd, float* scale,
                                    float* shift, int C, double count, float eps, float momentum, int upd, int nrep,
                                    int rep_stride) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), r0 = threadIdx.x & 15;
+  const bool live = c < C;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrep; ++r) { s1 += ssum[(size_t)r * rep_stride + c]; s2 += ssq[(size_t)r * rep_stride + c]; }
+  if (live)
+    for (int r = r0; r < nrep; r += 16) { s1 += ssum[(size_t)r * rep_stride + c]; s2 += ssq[(size_t)r * rep_stride + c]; }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) { s1 += shfl_xor_f64(s1, d); s2 += shfl_xor_f64(s2, d); }
+  if (!live || r0) return;
   const double mu = s1 / count;
   double var = s2 / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -68,7 +81,7 @@ hipError_t launch_bn_finalize(const double* ssum, const double* ssq, const float
                               float* run_mean, float* run_var, float* mean, float* rstd, float* scale, float* shift,
                               int C, double count, float eps, float momentum, int update_running, hipStream_t st,
                               int nrep, int rep_stride) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, ssum, ssq, gamma, beta, run_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ssum, ssq, gamma, beta, run_mean,
                      run_var, mean, rstd, scale, shift, C, count, eps, momentum, update_running, nrep < 1 ? 1 : nrep, rep_stride);
   return hipGetLastError();
 }
@@ -255,15 +268,19 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
   return hipGetLastError();
 }
 
-__global__ void bn_bwd_fold_kernel(const double* __restrict__ rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const double* __restrict__ rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta) {
+  // same shape as bn_finalize_kernel: 16 channels x 16 replica lanes, fixed xor tree
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), r0 = threadIdx.x & 15;
+  const bool live = c < C;
   double sb = 0.0, sg = 0.0;
-  for (int r = 0; r < nrep; ++r) { sb += rep[(size_t)r * rep_stride + c]; sg += rep[(size_t)r * rep_stride + C + c]; }
-  dbeta[c] = sb; dgamma[c] = sg;
+  if (live)
+    for (int r = r0; r < nrep; r += 16) { sb += rep[(size_t)r * rep_stride + c]; sg += rep[(size_t)r * rep_stride + C + c]; }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) { sb += shfl_xor_f64(sb, d); sg += shfl_xor_f64(sg, d); }
+  if (live && r0 == 0) { dbeta[c] = sb; dgamma[c] = sg; }
 }
 hipError_t launch_bn_bwd_fold(const double* rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, rep, nrep, rep_stride, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, rep, nrep, rep_stride, C, dgamma, dbeta);
   return hipGetLastError();
 }
 
