@@ -117,6 +117,18 @@ int  uwm_loss(const float* logits, int ld, const void* target, int target_dtype,
               float w_dice, float w_bce, float smooth, float eps, void* scratch, float* loss_out,
               float* dlogits, int ldd, float grad_scale, uwm_stream stream);
 
+/* The two halves of uwm_loss, for the data-parallel "global Dice" of SURVEY.md 8(e) (Dice is a ratio of batch sums, so the
+ * mean of per-rank Dice losses is NOT the Dice of the global batch): uwm_loss_sums leaves the local sums
+ * {sum p*t, sum p, sum t, sum bce} as four doubles in scratch[0..3]; the host all-reduces (SUM) those 32 bytes over the ranks
+ * (ncclAllReduce / torch.distributed on the same stream); uwm_loss_apply then evaluates loss_out and dlogits of the GLOBAL
+ * batch, npix_total = pixels over all ranks.  The parameter gradients of the ranks must then be SUMMED, not averaged: pass
+ * grad_scale = world_size here when the exchange averages.  npix_total == npix reproduces uwm_loss. */
+int  uwm_loss_sums(const float* logits, int ld, const void* target, int target_dtype, long long npix, void* scratch,
+                   uwm_stream stream);
+int  uwm_loss_apply(const float* logits, int ld, const void* target, int target_dtype, long long npix, long long npix_total,
+                    float w_dice, float w_bce, float smooth, float eps, const void* scratch, float* loss_out,
+                    float* dlogits, int ldd, float grad_scale, uwm_stream stream);
+
 /* out[N][4] int64 = tp, fp, fn, tn of (v >= threshold), v = sigmoid(logit) if apply_sigmoid else logit */
 int  uwm_stats(const float* logits, int ld, const void* target, int target_dtype, int N, long long hw,
                float threshold, int apply_sigmoid, long long* out, uwm_stream stream);

@@ -64,6 +64,8 @@ SIGNATURES = {
     "uwm_forward": (I, [P, P, P, P, Z, I, I, I, I, P]),
     "uwm_backward": (I, [P, P, P, I, I, P]),
     "uwm_loss": (I, [P, I, P, I, L, F, F, F, F, P, P, P, I, F, P]),
+    "uwm_loss_sums": (I, [P, I, P, I, L, P, P]),
+    "uwm_loss_apply": (I, [P, I, P, I, L, L, F, F, F, F, P, P, P, I, F, P]),
     "uwm_stats": (I, [P, I, P, I, I, L, F, I, P, P]),
     "uwm_threshold": (I, [P, I, L, F, I, P, P]),
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),

@@ -160,7 +160,8 @@ def train_command(args):
     wd, wb = _loss_weights(cfg)
     trainer = Trainer(model, w_dice=wd, w_bce=wb, smooth=float(cfg.LOSS.SMOOTH), lr=float(cfg.TRAIN.LR),
                       weight_decay=float(cfg.TRAIN.WEIGHT_DECAY), optimizer=cfg.OPTIMIZER.NAME,
-                      max_grad_norm=(float(cfg.TRAIN.GRADIENT_CLIP) if args.grad_clip else None))
+                      max_grad_norm=(float(cfg.TRAIN.GRADIENT_CLIP) if args.grad_clip else None),
+                      global_dice=bool(getattr(args, "global_dice", False)))
     criterion = get_loss_function(cfg)
     sched = _make_scheduler(cfg, trainer.opt)
     start_epoch, best = 0, float("inf")
@@ -279,6 +280,8 @@ def main(argv=None):
     tp.add_argument("--model", choices=["Unet", "UnetPlusPlus"], default=None, help="MODEL.NAME (reference default: UnetPlusPlus)")
     tp.add_argument("--grad-clip", action="store_true", help="honour TRAIN.GRADIENT_CLIP (the reference defines but never applies it)")
     tp.add_argument("--optimizer", choices=["Adam", "SGD"], default=None, help="OPTIMIZER.NAME")
+    tp.add_argument("--global-dice", action="store_true",
+                    help="data-parallel runs: Dice of the GLOBAL batch (loss sums all-reduced) instead of the mean of per-rank Dice losses")
     tp.add_argument("--lr-scheduler", choices=["ReduceLROnPlateau", "CosineAnnealingLR", "none"], default=None, help="OPTIMIZER.LR_SCHEDULER")
     tp.add_argument("--checkpoint-dir", type=str, default=None, help="TRAIN.CHECKPOINT_DIR")
     pp = sub.add_parser("predict")

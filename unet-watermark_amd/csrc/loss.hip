@@ -78,11 +78,12 @@ __global__ void loss_finalize_kernel(const double* scratch, double n, float w_di
 }
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ logits, int ld, const void* __restrict__ target,
-                                                        int tdtype, size_t n, const double* scratch, float w_dice, float w_bce,
+                                                        int tdtype, size_t n, double ntotal, const double* scratch, float w_dice, float w_bce,
                                                         float smooth, float eps, float* __restrict__ dlogits, int ldd,
                                                         float gscale) {
-  const LossCoef c = loss_coef(scratch, (double)n, smooth, eps);
-  const float A = (float)c.A, B = (float)c.B, invn = (float)(1.0 / (double)n);
+  // ntotal: pixels behind the sums in `scratch` (== n unless the sums were all-reduced over data-parallel ranks)
+  const LossCoef c = loss_coef(scratch, ntotal, smooth, eps);
+  const float A = (float)c.A, B = (float)c.B, invn = (float)(1.0 / ntotal);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float x = logits[i * ld];
     const float t = load_target(target, tdtype, i);
@@ -97,18 +98,30 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
   }
 }
 
+static unsigned loss_blocks(size_t n) { size_t nb = (n + 1023) / 1024; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1; return (unsigned)nb; }
+// first half of the loss: scratch4 = local {sum p*t, sum p, sum t, sum bce}
+hipError_t launch_loss_sums(const float* logits, int ld, const void* target, int tdtype, size_t n, double* scratch4, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(scratch4, 0, 4 * sizeof(double), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(loss_blocks(n)), dim3(256), 0, st, logits, ld, target, tdtype, n, scratch4);
+  return hipGetLastError();
+}
+// second half: loss value and dL/dlogits from the sums in scratch4, which cover ntotal pixels (>= n when all-reduced)
+hipError_t launch_loss_apply(const float* logits, int ld, const void* target, int tdtype, size_t n, double ntotal, float w_dice, float w_bce,
+                             float smooth, float eps, const double* scratch4, float* loss_out3, float* dlogits, int ldd,
+                             float grad_scale, hipStream_t st) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, scratch4, ntotal, w_dice, w_bce, smooth, eps, loss_out3);
+  if (dlogits)
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(loss_blocks(n)), dim3(256), 0, st, logits, ld, target, tdtype, n, ntotal, scratch4, w_dice,
+                       w_bce, smooth, eps, dlogits, ldd, grad_scale);
+  return hipGetLastError();
+}
 hipError_t launch_loss(const float* logits, int ld, const void* target, int tdtype, size_t n, float w_dice, float w_bce,
                        float smooth, float eps, double* scratch4, float* loss_out3, float* dlogits, int ldd,
                        float grad_scale, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(scratch4, 0, 4 * sizeof(double), st);
+  hipError_t e = launch_loss_sums(logits, ld, target, tdtype, n, scratch4, st);
   if (e != hipSuccess) return e;
-  size_t nb = (n + 1023) / 1024; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, logits, ld, target, tdtype, n, scratch4);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, scratch4, (double)n, w_dice, w_bce, smooth, eps, loss_out3);
-  if (dlogits)
-    hipLaunchKernelGGL(loss_grad_kernel, dim3((unsigned)nb), dim3(256), 0, st, logits, ld, target, tdtype, n, scratch4, w_dice,
-                       w_bce, smooth, eps, dlogits, ldd, grad_scale);
-  return hipGetLastError();
+  return launch_loss_apply(logits, ld, target, tdtype, n, (double)n, w_dice, w_bce, smooth, eps, scratch4, loss_out3, dlogits, ldd, grad_scale, st);
 }
 
 // ---------------------------------------------------------------- tp / fp / fn / tn per image (int64)

@@ -248,6 +248,10 @@ hipError_t launch_rowscale(const float* g, const float* rowscale, int N, size_t 
 hipError_t launch_loss(const float* logits, int ld, const void* target, int tdtype, size_t npix_total,
                        float w_dice, float w_bce, float smooth, float eps, double* scratch4, float* loss_out3,
                        float* dlogits, int ldd, float grad_scale, hipStream_t st);
+hipError_t launch_loss_sums(const float* logits, int ld, const void* target, int tdtype, size_t n, double* scratch4, hipStream_t st);
+hipError_t launch_loss_apply(const float* logits, int ld, const void* target, int tdtype, size_t n, double ntotal, float w_dice, float w_bce,
+                             float smooth, float eps, const double* scratch4, float* loss_out3, float* dlogits, int ldd,
+                             float grad_scale, hipStream_t st);
 hipError_t launch_stats(const float* logits, int ld, const void* target, int tdtype, int N, size_t hw,
                         float thr, int apply_sigmoid, long long* out4, hipStream_t st);
 hipError_t launch_threshold(const float* logits, int ld, size_t npix, float thr, int apply_sigmoid,

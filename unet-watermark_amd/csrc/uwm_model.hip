@@ -1248,6 +1248,22 @@ int uwm_loss(const float* logits, int ld, const void* target, int tdt, long long
                    ldd, grad_scale, (hipStream_t)stream));
   return 0;
 }
+int uwm_loss_sums(const float* logits, int ld, const void* target, int tdt, long long npix, void* scratch, uwm_stream stream) {
+  if (!logits || !target || !scratch || npix <= 0 || ld < 1) return fail("uwm_loss_sums: bad argument");
+  if (tdt < 0 || tdt > 3) return fail("uwm_loss_sums: unsupported target dtype %d", tdt);
+  LCHK(launch_loss_sums(logits, ld, target, tdt, (size_t)npix, (double*)scratch, (hipStream_t)stream));
+  return 0;
+}
+int uwm_loss_apply(const float* logits, int ld, const void* target, int tdt, long long npix, long long npix_total, float w_dice,
+                   float w_bce, float smooth, float eps, const void* scratch, float* loss_out, float* dlogits, int ldd,
+                   float grad_scale, uwm_stream stream) {
+  if (!logits || !target || !scratch || !loss_out || npix <= 0 || npix_total < npix || ld < 1) return fail("uwm_loss_apply: bad argument");
+  if (tdt < 0 || tdt > 3) return fail("uwm_loss_apply: unsupported target dtype %d", tdt);
+  if (dlogits && ldd < 1) return fail("uwm_loss_apply: bad dlogits stride");
+  LCHK(launch_loss_apply(logits, ld, target, tdt, (size_t)npix, (double)npix_total, w_dice, w_bce, smooth, eps, (const double*)scratch,
+                         loss_out, dlogits, ldd, grad_scale, (hipStream_t)stream));
+  return 0;
+}
 int uwm_stats(const float* logits, int ld, const void* target, int tdt, int N, long long hw, float thr, int sig,
               long long* out, uwm_stream stream) {
   if (!logits || !target || !out || N < 1 || hw < 1) return fail("uwm_stats: bad argument");

@@ -266,8 +266,13 @@ class Trainer:
     def __init__(self, model, w_dice: float = 1.0, w_bce: float = 0.0, smooth: float = 1e-5, eps: float = 1e-7,
                  lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0,
                  group=None, overlap_comm: bool = True, force_ddp: bool = False, max_grad_norm=None,
-                 optimizer: str = "Adam", momentum: float = 0.9):
+                 optimizer: str = "Adam", momentum: float = 0.9, global_dice: bool = False):
         self.model = model
+        # global_dice (SURVEY.md 8(e) caveat): Dice is a ratio of batch sums, so DDP's mean of per-rank Dice losses is not the
+        # Dice of the global batch.  With the flag the four loss sums (32 bytes) are all-reduced between the loss's two
+        # halves and every rank back-propagates the GLOBAL loss: an N-rank run then optimises exactly what one process
+        # with the concatenated batch would (BatchNorm statistics stay per rank, as under torch DDP).
+        self.global_dice = bool(global_dice)
         self.w_dice, self.w_bce, self.smooth, self.eps = float(w_dice), float(w_bce), float(smooth), float(eps)
         if optimizer == "Adam":          # cfg.OPTIMIZER.NAME (/root/reference/src/train.py:266-279)
             self.opt = FusedAdam(model, lr=lr, betas=betas, eps=adam_eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
@@ -308,10 +313,20 @@ class Trainer:
         if t.numel() != n * h * w:
             raise ValueError(f"masks have {t.numel()} elements, expected {n * h * w}")
         st = C.c_void_p(L.stream_ptr(dev))
-        L.check(L.lib().uwm_loss(C.c_void_p(logits.data_ptr()), m._cp, C.c_void_p(t.data_ptr()), L.target_dtype_code(t),
-                                 n * h * w, self.w_dice, self.w_bce, self.smooth, self.eps,
-                                 C.c_void_p(self._scratch.data_ptr()), C.c_void_p(self._loss.data_ptr()),
-                                 C.c_void_p(self._dl.data_ptr()), m._cp, 1.0, st))
+        if self.global_dice and self.ddp:
+            lp, tp, tdt = C.c_void_p(logits.data_ptr()), C.c_void_p(t.data_ptr()), L.target_dtype_code(t)
+            L.check(L.lib().uwm_loss_sums(lp, m._cp, tp, tdt, n * h * w, C.c_void_p(self._scratch.data_ptr()), st))
+            dist.all_reduce(self._scratch[:4], group=self.group)          # SUM of {sum p*t, sum p, sum t, sum bce}
+            # the ranks' parameter gradients of the global loss ADD UP; the exchange below averages, hence grad_scale = world
+            L.check(L.lib().uwm_loss_apply(lp, m._cp, tp, tdt, n * h * w, n * h * w * self.world, self.w_dice, self.w_bce,
+                                           self.smooth, self.eps, C.c_void_p(self._scratch.data_ptr()),
+                                           C.c_void_p(self._loss.data_ptr()), C.c_void_p(self._dl.data_ptr()), m._cp,
+                                           float(self.world), st))
+        else:
+            L.check(L.lib().uwm_loss(C.c_void_p(logits.data_ptr()), m._cp, C.c_void_p(t.data_ptr()), L.target_dtype_code(t),
+                                     n * h * w, self.w_dice, self.w_bce, self.smooth, self.eps,
+                                     C.c_void_p(self._scratch.data_ptr()), C.c_void_p(self._loss.data_ptr()),
+                                     C.c_void_p(self._dl.data_ptr()), m._cp, 1.0, st))
         nst = len(m.stages)
         if self.ddp:
             if self._reducer is None or self._reducer.flat.data_ptr() != m.flat_grads().data_ptr():
