@@ -136,7 +136,7 @@ def collect_prof(L, steps):
         cnt, ms, fl, by = prof[c * 4], prof[c * 4 + 1], prof[c * 4 + 2], prof[c * 4 + 3]
         if cnt > 0 and ms > 0:
             name = L.lib().uwm_prof_class_name(c).decode()
-            wino = "wino" in name       # Winograd F(2x2,3x3): the MFMA pipe executes 16 multiplies per 36 direct ones
+            wino = "wino" in name or "up2" in name       # Winograd F(2x2,3x3) and the sub-pixel form of conv-after-upsample: the MFMA pipe executes 16 multiplies per 36 direct ones
             ents[name] = {"kernel": name, "launches_per_step": cnt / max(1, steps), "avg_us": round(1e3 * ms / cnt, 2),
                           "ms_per_step": round(ms / max(1, steps), 3),
                           "mfma_tflops": round(fl / ms / 1e9 / (WINO_RATIO if wino else 1.0), 2),

@@ -10,16 +10,18 @@ dev = torch.device("cuda:0")
 shapes = {"layer1": (16, 64, 64, 128, 128), "layer2": (16, 128, 128, 64, 64), "layer3": (16, 256, 256, 32, 32),
           "layer4": (16, 512, 512, 16, 16), "dec0c1": (16, 768, 256, 32, 32), "dec0c2": (16, 256, 256, 32, 32),
           "dec1c1": (16, 384, 128, 64, 64), "dec2c1": (16, 192, 64, 128, 128), "dec3c1": (16, 128, 32, 256, 256),
-          "dec3c2": (16, 32, 32, 256, 256), "dec4c1": (16, 32, 16, 512, 512), "dec4c2": (16, 16, 16, 512, 512)}
+          "dec3c2": (16, 32, 32, 256, 256), "dec4c1": (16, 32, 16, 512, 512), "dec4c2": (16, 16, 16, 512, 512),
+          "dec4c1u": (16, 32, 16, 512, 512)}     # the real decoder block 4 conv1: input is a 256x256 tensor, nearest-x2 upsampled by the loader
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [300, -2]
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, (n, cin, cout, h, w) in shapes.items():
     if only and name not in only: continue
-    x = torch.randn(n, h, w, cin, device=dev)
+    up = 1 if name.endswith("u") else 0
+    x = torch.randn(n, h >> up, w >> up, cin, device=dev)
     kpad = (9 * cin + 31) // 32 * 32
     wt = torch.randn(cout, kpad, device=dev) * 0.05
     y = torch.empty(n, h, w, cout, device=dev)
-    s0 = src(x)
+    s0 = src(x, up=up)
     line = f"{name:8s}"
     for cfg in cfgs:
         c = cfg

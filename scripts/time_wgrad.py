@@ -7,15 +7,16 @@ from unet_watermark_amd import _lib as L
 dev = torch.device("cuda:0")
 shapes = {"layer1": (16, 64, 64, 128, 128), "layer2": (16, 128, 128, 64, 64), "layer3": (16, 256, 256, 32, 32),
           "layer4": (16, 512, 512, 16, 16), "dec0c1": (16, 768, 256, 32, 32), "dec1c1": (16, 384, 128, 64, 64),
-          "dec2c1": (16, 192, 64, 128, 128), "dec3c1": (16, 128, 32, 256, 256), "dec4c1": (16, 32, 16, 512, 512), "dec4c2": (16, 16, 16, 512, 512)}
+          "dec2c1": (16, 192, 64, 128, 128), "dec3c1": (16, 128, 32, 256, 256), "dec4c1": (16, 32, 16, 512, 512), "dec4c2": (16, 16, 16, 512, 512), "dec4c1u": (16, 32, 16, 512, 512)}
 force = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, (n, cin, cout, h, w) in shapes.items():
     if only and name not in only: continue
-    x = torch.randn(n, h, w, cin, device=dev); dy = torch.randn(n, h, w, cout, device=dev)
+    up = 1 if name.endswith("u") else 0
+    x = torch.randn(n, h >> up, w >> up, cin, device=dev); dy = torch.randn(n, h, w, cout, device=dev)
     kpad = (9 * cin + 31) // 32 * 32
     dw = torch.zeros(cout, kpad, device=dev)
-    s0 = src(x)
+    s0 = src(x, up=up)
     def run():
         L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dy), n, h, w, cout, cout, kpad, 3, 3, 1, 1, P(dw), force, stream()))
     for _ in range(2): run()

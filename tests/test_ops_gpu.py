@@ -137,6 +137,36 @@ def test_conv_winograd_bf16x3_lazy_upsample_concat(cuda):
     assert err < 1e-4 * max(1.0, float(y.abs().max())), err
 
 
+@pytest.mark.parametrize("n,hs,ws,lazy,cfg", [(2, 16, 32, True, 700), (1, 8, 16, False, 700), (3, 24, 48, True, -1)])
+def test_conv_up2_subpixel_forward(cuda, n, hs, ws, lazy, cfg):
+    """decoder block 4 conv1: 3x3 over a nearest-x2 upsampled (lazily normalised + ReLU-ed) 32-channel tensor, 16 outputs,
+    as four 2x2 parity-class convolutions on the low-resolution tensor (conv_up2.hip); cfg -1 = the auto route must pick it.
+    Output and BatchNorm statistics against torch's interpolate + conv2d."""
+    L = lib()
+    g = torch.Generator().manual_seed(23 + hs)
+    a = torch.randn(n, 32, hs, ws, generator=g)
+    sc = torch.rand(32, generator=g) + 0.5; sh = torch.randn(32, generator=g) * 0.3
+    wt = torch.randn(16, 32, 3, 3, generator=g) * 0.08
+    act = torch.relu(a * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if lazy else a
+    y = F.conv2d(F.interpolate(act.double(), scale_factor=2, mode="nearest"), wt.double(), None, padding=1)
+    ad = nhwc(a.to(cuda)); wp, kpad = pack_w(wt.to(cuda))
+    out = torch.full((n, 2 * hs, 2 * ws, 16), float("nan"), device=cuda)
+    stats = torch.zeros(32, dtype=torch.float64, device=cuda)
+    t = [sc.to(cuda), sh.to(cuda)]                   # (src() keeps nothing alive)
+    s0 = src(ad, t[0], t[1], relu=1, up=1) if lazy else src(ad, up=1)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), 16, kpad, 3, 3, 1, 1, n, 16, None, P(out), P(stats), cfg, stream()))
+    torch.cuda.synchronize()
+    got = nchw(out.cpu(), 16).double()
+    err = float((got - y).abs().max())
+    assert err < 2e-5 * max(1.0, float(y.abs().max())), err
+    assert torch.allclose(stats[:16].cpu(), y.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(stats[16:].cpu(), (y * y).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    # the Winograd route on the same operands (what this kernel replaces) agrees to fp32 rounding
+    out2 = torch.empty_like(out)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), 16, kpad, 3, 3, 1, 1, n, 16, None, P(out2), None, 300, stream()))
+    assert float((out2 - out).abs().max()) < 5e-5 * max(1.0, float(y.abs().max()))
+
+
 def test_conv_winograd_error_vs_fp64(cuda):
     """Winograd's transforms cost a little accuracy; measured against an fp64 convolution the error must stay
     within 4x that of the direct fp32 kernel (and far inside the 1e-3 logit budget)."""
@@ -384,6 +414,39 @@ def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
     assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
 
 
+@pytest.mark.parametrize("n,hs,ws", [(2, 8, 16), (3, 12, 32)])
+def test_wgrad_up2_subpixel(cuda, n, hs, ws):
+    """decoder block 4 conv1 weight gradient (32 upsampled channels -> 16) in sub-pixel form (conv_up2.hip: 16 class products
+    over the low-resolution tensor, folded into the nine taps by the reduce kernel) against autograd, and bit-identical
+    between two launches (fixed-order partial sums)."""
+    L = lib()
+    g = torch.Generator().manual_seed(31 + hs)
+    d = torch.randn(n, 32, hs, ws, generator=g)
+    sc0, sh0 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    a0 = torch.relu(d * sc0[:, None, None] + sh0[:, None, None])
+    wt = (torch.randn(16, 32, 3, 3, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(F.interpolate(a0, scale_factor=2, mode="nearest"), wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dd, dyd = nhwc(d).to(cuda), nhwc(dy).to(cuda)
+    kpad = rup(9 * 32, 32)
+    t = [sc0.to(cuda), sh0.to(cuda)]                 # (src() keeps nothing alive)
+    s0 = src(dd, t[0], t[1], relu=1, up=1)
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(16, kpad, device=cuda)
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, 2 * hs, 2 * ws, 16, 16, kpad, 3, 3, 1, 1, P(dw), 0, stream()))
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    got = unpack_w(outs[0], 16, 32, 3, 3)
+    assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+    # the generic route (force_igemm = 1) on the same operands
+    dw2 = torch.zeros(16, kpad, device=cuda)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, 2 * hs, 2 * ws, 16, 16, kpad, 3, 3, 1, 1, P(dw2), 1, stream()))
+    assert (dw2.cpu() - outs[0]).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+
+
 def test_maxpool_ties_and_lazy_input(cuda):
     """3x3 s2 p1 max-pool over relu(bn(y)): post-ReLU zeros tie; the FIRST max in scan order wins,
     as torch's CPU kernel does, so the argmax (and with it the backward) matches."""
@@ -470,7 +533,7 @@ def test_upsplit_matches_autograd(cuda):
     assert torch.equal(gs.cpu(), skip.grad.permute(0, 2, 3, 1).contiguous())
 
 
-@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 64, 32), (32, 0, 16), (128, 64, 64)])
+@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 64, 32), (32, 0, 16), (128, 64, 64)])      # (32, 0, 16): conv_up2_dgrad_kernel (sub-pixel form)
 def test_dgrad_with_fused_concat_split(cuda, c0, c1, cout):
     """decoder conv1 backward: dgrad (Winograd) writes the 2x2-pooled, ReLU-masked gradient of up(prev) and the skip
     gradient straight from its epilogue — must equal autograd through cat(interpolate(relu(bn(prev))), skip) -> conv."""

@@ -308,8 +308,10 @@ int device_cu_count() {
 // mirrors the auto routing below: true when launch_conv(a, st) ends on a kernel whose epilogue can carry the fused
 // BatchNorm-backward sums (ConvArgs::bnb_*): conv_wino_kernel<NI>, conv_wino_x3_kernel, conv_patch16_kernel, conv_head_dgrad_kernel
 bool conv_routes_to_wino(const ConvArgs& a) {
-  if (a.out_up) return a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a);
+  static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr;
+  if (a.out_up) return (!no_up2 && conv_up2_dgrad_applicable(a)) || (a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a));
   static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
+  if (!no_up2 && conv_up2_applicable(a)) return false;
   if (!no_head && conv_head_applicable(a)) return false;
   if (!no_head && conv_head_dgrad_applicable(a)) return true;
   if (wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a))
@@ -326,14 +328,19 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
     fprintf(stderr, "conv %s N=%d Ctot=%d(C0=%d up=%d) Cout=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d smul=%d sdiv=%d wino=%d gflop=%.2f\n",
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
             (int)(cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)), a.flops * 1e-9);
+  if (cfg == 700) return launch_conv_up2(a, st);
   if (cfg == 500) return launch_conv_head(a, st);
   if (cfg == 400) return launch_conv_wino_x3(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
-  if (a.out_up) {                                                  // fused concat split: Winograd epilogues only
+  if (a.out_up) {                                                  // fused concat split: Winograd epilogues (and the sub-pixel dgrad of conv_up2.hip)
+    static const bool no_up2d = getenv("UWM_NO_UP2") != nullptr;
+    if (cfg < 0 && !no_up2d && conv_up2_dgrad_applicable(a)) return launch_conv_up2_dgrad(a, st);
     if (a.prec == 1) return launch_conv_wino_x3(a, st);
     return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;
   }
   if (cfg == 200) return launch_conv_patch16(a, st);
+  static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr;
+  if (cfg < 0 && !no_up2 && conv_up2_applicable(a)) return launch_conv_up2(a, st);      // sub-pixel decomposition: Winograd's 2.25x without transforms
   static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
   if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);
   if (cfg < 0 && !no_head && conv_head_dgrad_applicable(a)) return launch_conv_head_dgrad(a, st);      // few channels -> <= 4 classes: HBM streaming kernel

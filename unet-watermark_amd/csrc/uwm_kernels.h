@@ -100,7 +100,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 34 };   // 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 37 };   // 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -133,6 +133,12 @@ size_t wgrad_wino_scratch_floats();                         // workspace the mod
 float* wgrad_op_scratch();                                  // the same, for the single-operator entry points (cached per device)
 bool wgrad_c16_applicable(const WgradArgs& a);              // 16-channel full-resolution layers and the head (wgrad_c16.hip)
 hipError_t launch_wgrad_c16(const WgradArgs& a, hipStream_t st);
+bool wgrad_up2_applicable(const WgradArgs& a);              // wgrad of conv_up2.hip's layer (nearest-x2 upsampled 32-channel input, 16 outputs)
+hipError_t launch_wgrad_up2(const WgradArgs& a, hipStream_t st);
+bool conv_up2_applicable(const ConvArgs& a);              // 3x3 over a nearest-x2 upsampled 32-channel input, 16 outputs (conv_up2.hip)
+hipError_t launch_conv_up2(const ConvArgs& a, hipStream_t st);
+bool conv_up2_dgrad_applicable(const ConvArgs& a);        // its dgrad wrt the low-resolution input, concat-split epilogue contract (ConvArgs::out_up)
+hipError_t launch_conv_up2_dgrad(const ConvArgs& a, hipStream_t st);
 bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);
