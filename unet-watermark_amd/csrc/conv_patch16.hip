@@ -19,53 +19,148 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kT = 16, kP = kT + 2, kPPix = kP * kP;      // 16x16 output pixels, 18x18 = 324 patch pixels
 constexpr int kWLd = 148;                                  // weight row stride in floats (37 16-B units: odd)
 
+// Persistent since round 2: a workgroup walks tiles bid, bid + grid, ... with the patch double-buffered (the next tile's
+// global loads are issued before this tile's MFMAs and land in registers behind them; one barrier per tile), the weight
+// panel is staged once, and the BatchNorm statistics leave as ONE set of atomics per workgroup.  The one-tile-per-workgroup
+// form (load -> barrier -> 144 MFMAs -> store, five workgroups per CU to overlap) measured 266 us on decoder block 4 conv2.
 template <int BN>
-__global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const ConvArgs a, int ntiles) {
   constexpr int NI = BN / 16;
   constexpr int MI = 4;                          // 4 waves x 4 pixel rows
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const Ps = smem;                        // [324][16]
-  float* const Ws = smem + kPPix * 16;           // [BN][148]
+  float* const Ws = smem;                        // [BN][148]
+  float* const Pbuf = smem + BN * kWLd;          // [2][324][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int lrow = lane & 15, lq = lane >> 4;
-
-  const unsigned nblk = gridDim.x, bid = blockIdx.x;
-  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tilesN = (a.Cout + BN - 1) / BN;
   const int tilesW = (a.Wo + kT - 1) / kT, tilesH = (a.Ho + kT - 1) / kT;
-  const int tn = tile % tilesN; tile /= tilesN;
-  const int tw = tile % tilesW; tile /= tilesW;
-  const int th = tile % tilesH; const int n = tile / tilesH;
-  const int n0 = tn * BN, h0 = th * kT, w0 = tw * kT;
   const bool mirror = a.rmul < 0;                // dgrad: tap (r,s) reads patch (ty+2-r, tx+2-s)
 
-  // ---- stage the patch: 324 pixels x 4 units
+  // ---- per-thread staging geometry (tile-invariant): 324 pixels x 4 units = 1296 units, 6 rounds
+  const int chu = tid & 3;
   const bool has = a.s0.scale != nullptr;
-  for (int u = tid; u < kPPix * 4; u += 256) {
-    const int pp = u >> 2, chu = u & 3;
-    const int py = pp / kP, px = pp - py * kP;
-    const int hl = h0 - 1 + py, wl = w0 - 1 + px;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl) {
-      v = *(const f4*)(a.s0.ptr + ((size_t)((size_t)n * a.s0.H + hl) * a.s0.W + wl) * a.s0.C + chu * 4);
+  f4 lsc = {1.f, 1.f, 1.f, 1.f}, lsh = {0.f, 0.f, 0.f, 0.f};
+  if (has) { lsc = *(const f4*)(a.s0.scale + chu * 4); lsh = *(const f4*)(a.s0.shift + chu * 4); }
+  int spy[6], spx[6], spos[6];
+#pragma unroll
+  for (int rd = 0; rd < 6; ++rd) {
+    const int pp = min((rd * 256 + tid) >> 2, kPPix - 1);
+    spy[rd] = pp / kP; spx[rd] = pp - spy[rd] * kP;
+    spos[rd] = pp * 16 + ((chu ^ ((pp >> 2) & 3)) << 2);
+  }
+  const bool last_live = (5 * 256 + tid) < kPPix * 4;
+  f4 pv[6]; unsigned pok = 0;
+  auto tile_origin = [&](int t, int& n, int& n0, int& h0, int& w0) {
+    const int tn = t % tilesN; t /= tilesN;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; n = t / tilesH;
+    n0 = tn * BN; h0 = th * kT; w0 = tw * kT;
+  };
+  auto patch_load = [&](int t) {
+    int n, n0, h0, w0; tile_origin(t, n, n0, h0, w0);
+    pok = 0;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      const int hl = h0 - 1 + spy[rd], wl = w0 - 1 + spx[rd];
+      const bool ok = hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+      pv[rd] = *(const f4*)(a.s0.ptr + ((size_t)((size_t)n * a.s0.H + hc) * a.s0.W + wc) * a.s0.C + chu * 4);
+      pok |= (ok ? 1u : 0u) << rd;
+    }
+  };
+  auto patch_store = [&](int buf) {
+    float* const pb_ = Pbuf + buf * kPPix * 16;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      f4 v = pv[rd];
       if (has) {
-        v = v * *(const f4*)(a.s0.scale + chu * 4) + *(const f4*)(a.s0.shift + chu * 4);
+        v = v * lsc + lsh;
         if (a.s0.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
+      if (!((pok >> rd) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (rd < 5 || last_live) *(f4*)(pb_ + spos[rd]) = v;
     }
-    *(f4*)(Ps + pp * 16 + ((chu ^ ((pp >> 2) & 3)) << 2)) = v;
-  }
-  // ---- stage the weight panel: BN rows x 36 units (k = tap*16 + c)
-  for (int u = tid; u < BN * 36; u += 256) {
-    const int row = u / 36, ku = u - row * 36;
-    const int co = n0 + row;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (co < a.wrows) v = *(const f4*)(a.w + (size_t)co * a.Kpad + ku * 4);
-    *(f4*)(Ws + row * kWLd + ku * 4) = v;
-  }
+  };
+
+  // ---- stage the weight panel of the FIRST tile's channel block (tilesN == 1 in every model layer; else re-staged per tile)
+  int t = blockIdx.x;
+  int wn0 = -1;
+  auto stage_w = [&](int n0) {
+    for (int u = tid; u < BN * 36; u += 256) {
+      const int row = u / 36, ku = u - row * 36;
+      const int co = n0 + row;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (co < a.wrows) v = *(const f4*)(a.w + (size_t)co * a.Kpad + ku * 4);
+      *(f4*)(Ws + row * kWLd + ku * 4) = v;
+    }
+    wn0 = n0;
+  };
+  { int n, n0, h0, w0; tile_origin(t, n, n0, h0, w0); stage_w(n0); }
+  patch_load(t);
+  patch_store(0);
   __syncthreads();
+
+  const bool do_stats = a.ssum != nullptr;
+  f4 ps_[NI], pq_[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { ps_[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq_[j] = ps_[j]; }
+  // fused BatchNorm-backward sums (uwm_kernels.h ConvArgs::bnb_*): second sum = v * yhat of the mask tensor
+  const bool bnb = a.bnb_mean != nullptr;
+  int stat_n0 = -1;                              // channel block the running sums belong to (flushed when it changes)
+
+  auto flush_stats = [&](int n0) {               // 16 pixel lanes -> 4 waves (LDS, the buffer the NEXT tile does not use yet) -> fp64 atomics
+    const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sv = ps_[j][e], qv = pq_[j][e];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { sv += __shfl_xor(sv, d); qv += __shfl_xor(qv, d); }
+        ps_[j][e] = sv; pq_[j][e] = qv;
+      }
+    __syncthreads();
+    float* red = Ws;                             // [4 waves][BN][2]  (re-staged afterwards if another tile follows)
+    if (lrow == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cl = j * 16 + lq * 4 + e;
+          red[(wm * BN + cl) * 2 + 0] = ps_[j][e];
+          red[(wm * BN + cl) * 2 + 1] = pq_[j][e];
+        }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int co = n0 + tid;
+      if (co < a.Cout) {
+        double sv = 0.0, qv = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sv += (double)red[(w * BN + tid) * 2]; qv += (double)red[(w * BN + tid) * 2 + 1]; }
+        atomicAdd(a.ssum + srep_off + co, sv);
+        atomicAdd(a.ssq + srep_off + co, qv);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { ps_[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq_[j] = ps_[j]; }
+  };
+
+  for (int it = 0; t < ntiles; ++it, t += gridDim.x) {
+    const int cur = it & 1;
+    const int tnx = t + (int)gridDim.x;
+    patch_load(tnx < ntiles ? tnx : t);          // (last tile: harmless re-read)
+    int n, n0, h0, w0; tile_origin(t, n, n0, h0, w0);
+    if (n0 != wn0) {                             // another channel block (BN < Cout: not a model shape): flush its sums, re-stage the panel
+      if (do_stats && stat_n0 >= 0) flush_stats(stat_n0);
+      __syncthreads();
+      stage_w(n0);
+      __syncthreads();
+    }
+    stat_n0 = n0;
+    const float* const Ps = Pbuf + cur * kPPix * 16;
 
   f4 acc[MI][NI];
 #pragma unroll
@@ -95,15 +190,6 @@ __global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
   }
 
   // ---------------- epilogue (same contract as conv_igemm_kernel) ----------------
-  const bool do_stats = a.ssum != nullptr;
-  // BatchNorm statistics go to one of a.srep copies (few-channel layers launch tens of thousands of workgroups:
-  // fp64 atomics on the same 2*C addresses serialise), bn_finalize adds the copies
-  const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
-  f4 ps_[NI], pq_[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) { ps_[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq_[j] = ps_[j]; }
-  // fused BatchNorm-backward sums (uwm_kernels.h ConvArgs::bnb_*): second sum = v * yhat of the mask tensor
-  const bool bnb = a.bnb_mean != nullptr;
   f4 bmu[NI], brs[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -137,48 +223,22 @@ __global__ __launch_bounds__(256) void conv_patch16_kernel(const ConvArgs a) {
       }
     }
   }
-  if (do_stats) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float sv = ps_[j][e], qv = pq_[j][e];
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { sv += __shfl_xor(sv, d); qv += __shfl_xor(qv, d); }
-        ps_[j][e] = sv; pq_[j][e] = qv;
-      }
-    __syncthreads();                         // everyone is done reading the patch / weights
-    float* red = smem;                       // [4 waves][BN][2]
-    if (lrow == 0) {
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int cl = j * 16 + lq * 4 + e;
-          red[(wm * BN + cl) * 2 + 0] = ps_[j][e];
-          red[(wm * BN + cl) * 2 + 1] = pq_[j][e];
-        }
-    }
+    patch_store(cur ^ 1);
     __syncthreads();
-    if (tid < BN) {
-      const int co = n0 + tid;
-      if (co < a.Cout) {
-        double sv = 0.0, qv = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { sv += (double)red[(w * BN + tid) * 2]; qv += (double)red[(w * BN + tid) * 2 + 1]; }
-        atomicAdd(a.ssum + srep_off + co, sv);
-        atomicAdd(a.ssq + srep_off + co, qv);
-      }
-    }
   }
+  if (do_stats && stat_n0 >= 0) flush_stats(stat_n0);
 }
 
 template <int BN>
 static hipError_t launch_p16(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesN = (a.Cout + BN - 1) / BN;
   const int tilesW = (a.Wo + kT - 1) / kT, tilesH = (a.Ho + kT - 1) / kT;
-  const size_t lds = (size_t)(kPPix * 16 + BN * kWLd) * sizeof(float);
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_patch16_kernel<BN>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+  const size_t lds = (size_t)(2 * kPPix * 16 + BN * kWLd) * sizeof(float);
+  const int ntiles = a.N * tilesH * tilesW * tilesN;
+  const int nwg = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();      // 2 resident workgroups per CU (191-220 VGPRs)
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_patch16_kernel<BN>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_patch16_kernel<BN>), dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
   return hipGetLastError();
 }
 
