@@ -171,10 +171,16 @@ hipError_t launch_maxpool_fwd(const Src& in, float* out, uint8_t* idx, int N, in
   return hipGetLastError();
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
+// bn_mean != nullptr: the masked gradient this kernel writes is the gradient wrt the output of the BatchNorm whose raw input
+// it has just read for the ReLU mask (the stem: conv -> bn -> relu -> maxpool), so the BatchNorm-backward sums (dbeta = sum g,
+// dgamma = sum g * yhat) are accumulated here, one of `srep` fp64 replicas per workgroup (folded by bn_bwd_fold_kernel):
+// bn_bwd_reduce's pass over both tensors disappears.  Needs gridDim.x * 256 to be a multiple of C/4 (a thread keeps its channels).
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
                                    const float* __restrict__ addend, const Src in, float* __restrict__ gin, int Ho,
-                                   int Wo, size_t total) {
+                                   int Wo, size_t total, const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd,
+                                   double* ssum, double* ssq, int srep, int sstride) {
   const int C4 = in.C / 4;
+  f4 sg = {0.f, 0.f, 0.f, 0.f}, sgy = {0.f, 0.f, 0.f, 0.f};
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     size_t p = i / C4;
@@ -201,17 +207,37 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t
       }
     }
     if (in.scale && in.relu) {
-      f4 z = *(const f4*)(in.ptr + i * 4) * *(const f4*)(in.scale + c) + *(const f4*)(in.shift + c);
+      const f4 yr = *(const f4*)(in.ptr + i * 4);
+      const f4 z = yr * *(const f4*)(in.scale + c) + *(const f4*)(in.shift + c);
       g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+      if (bn_mean) { sg += g; sgy += g * (yr - *(const f4*)(bn_mean + c)); }
     }
     *(f4*)(gin + i * 4) = g;
   }
+  if (bn_mean) {                                 // threads t, t + C4, ... of the workgroup share a channel quad (256 % C4 == 0)
+    __shared__ float red[256 * 8];
+    const int c = (int)(threadIdx.x % C4) * 4;
+    sgy = sgy * *(const f4*)(bn_rstd + c);
+    float* r = red + threadIdx.x * 8;
+    r[0] = sg.x; r[1] = sg.y; r[2] = sg.z; r[3] = sg.w; r[4] = sgy.x; r[5] = sgy.y; r[6] = sgy.z; r[7] = sgy.w;
+    __syncthreads();
+    const size_t srep_off = srep > 1 ? (size_t)(blockIdx.x & (unsigned)(srep - 1)) * sstride : 0;
+    const int tr = 256 / C4;
+    for (int t = threadIdx.x; t < C4 * 8; t += 256) {
+      const int q = t / 8, e = t % 8;
+      double acc = 0.0;
+      for (int k = 0; k < tr; ++k) acc += (double)red[(k * C4 + q) * 8 + e];
+      if (e < 4) atomicAdd(ssum + srep_off + q * 4 + e, acc); else atomicAdd(ssq + srep_off + q * 4 + (e - 4), acc);
+    }
+  }
 }
 hipError_t launch_maxpool_bwd(const float* gout, const uint8_t* idx, const float* addend, const Src& in, float* gin,
-                              int N, int Ho, int Wo, hipStream_t st) {
+                              int N, int Ho, int Wo, hipStream_t st, const float* bn_mean, const float* bn_rstd, double* ssum,
+                              double* ssq, int srep, int sstride) {
   const size_t total = (size_t)N * in.H * in.W * (in.C / 4);
+  if (bn_mean && (!bn_rstd || !ssum || !ssq || !in.scale || !in.relu || (in.C & 3) || 256 % (in.C / 4))) return hipErrorInvalidValue;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblocks(total, 256)), dim3(256), 0, st, gout, idx, addend, in, gin, Ho,
-                     Wo, total);
+                     Wo, total, bn_mean, bn_rstd, ssum, ssq, srep, sstride);
   return hipGetLastError();
 }
 

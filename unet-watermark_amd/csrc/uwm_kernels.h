@@ -182,8 +182,9 @@ hipError_t launch_residual(const float* y, const float* s2, const float* b2, con
                            const float* bd, float* out, size_t npix, int C, hipStream_t st);
 hipError_t launch_maxpool_fwd(const Src& in, float* out, uint8_t* idx, int N, int Ho, int Wo, hipStream_t st);
 // g_in = (maxpool_bwd(g_out, idx) + addend) masked by relu(in.raw*scale+shift) > 0
-hipError_t launch_maxpool_bwd(const float* gout, const uint8_t* idx, const float* addend, const Src& in,
-                              float* gin, int N, int Ho, int Wo, hipStream_t st);
+hipError_t launch_maxpool_bwd(const float* gout, const uint8_t* idx, const float* addend, const Src& in, float* gin,
+                              int N, int Ho, int Wo, hipStream_t st, const float* bn_mean = nullptr, const float* bn_rstd = nullptr,
+                              double* ssum = nullptr, double* ssq = nullptr, int srep = 0, int sstride = 0);   // bn_*: fused BatchNorm-backward sums of the masked output
 // BatchNorm backward: g = grad wrt BN output (already ReLU-masked), y = raw conv output
 hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mean, const float* rstd,
                                 double* dgamma, double* dbeta, size_t npix, int C, hipStream_t st);

@@ -1067,9 +1067,15 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     }
     if (s == 0) {
       // maxpool backward (+ decoder skip gradient for f1) -> stem BN backward -> stem wgrad
+      // the masked gradient it writes is the gradient wrt the stem BatchNorm's output and it reads that BatchNorm's raw input
+      // for the mask anyway: the BatchNorm-backward sums ride along (replicas of the forward statistics, re-zeroed above)
+      const BNL& sb = m->bns[m->convs[m->stem].bn];
+      static const bool no_fuse = getenv("UWM_NO_BN_FUSE") != nullptr;
+      const bool pool_sums = !no_fuse && f1.scale && f1.relu && sb.C == f1.C && (256 % (f1.C / 4)) == 0;
       LCHK(launch_maxpool_bwd(c.F(p.g_pool), (const uint8_t*)c.F(p.pool_idx), c.F(p.gskip[3]), f1, c.F(p.g[m->stem]), N,
-                              sh[0], sw[0], st));
-      LCHK(run_bn_bwd(c, m->stem, c.F(p.g[m->stem]), c.F(p.g[m->stem]), (size_t)N * h1 * w1));
+                              sh[0], sw[0], st, pool_sums ? c.F(sb.f_off) : nullptr, pool_sums ? c.F(sb.f_off) + sb.C : nullptr,
+                              c.D(sb.d_off) + 2 * sb.C, c.D(sb.d_off) + 3 * sb.C, sb.nrep, 2 * sb.C));
+      LCHK(run_bn_bwd(c, m->stem, c.F(p.g[m->stem]), c.F(p.g[m->stem]), (size_t)N * h1 * w1, pool_sums));
       Src x4 = mk_src(c.F(p.x4), m->CinP, H, W);
       LCHK(run_wgrad(c, m->stem, x4, nullptr, c.F(p.g[m->stem]), h1, w1));
     }
