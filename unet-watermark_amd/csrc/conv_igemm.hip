@@ -193,6 +193,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   f4 ps[NI], pq[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) { ps[j] = (f4){0.f, 0.f, 0.f, 0.f}; pq[j] = ps[j]; }
+  // fused BatchNorm-backward sums (uwm_kernels.h ConvArgs::bnb_*): second sum = v * yhat of the mask tensor (round 2: the 1x1 and
+  // stride-2 dgrads of the Bottleneck encoder feed bn2 / bn1 this way)
+  const bool bnb = a.bnb_mean != nullptr;
+  f4 bmu[NI], brs[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + (wn * NI + j) * 16 + lq * 4;
+    bmu[j] = brs[j] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (bnb && co < a.Cout) { bmu[j] = *(const f4*)(a.bnb_mean + co); brs[j] = *(const f4*)(a.bnb_rstd + co); }
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     int m = m0 + (wm * MI + i) * 16 + lrow;
@@ -210,14 +220,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         const size_t o = (size_t)m * a.Cout + co;
         if (a.bias) v += *(const f4*)(a.bias + co);
         if (a.addend) v += *(const f4*)(a.addend + o);
+        f4 yr = {0.f, 0.f, 0.f, 0.f};
         if (a.mask) {
           f4 mk = *(const f4*)(a.mask + o);
+          yr = mk;
           if (a.mscale) mk = mk * *(const f4*)(a.mscale + co) + *(const f4*)(a.mshift + co);
           v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
           v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
         }
         *(f4*)(a.out + o) = v;
-        ps[j] += v; pq[j] += v * v;
+        ps[j] += v; pq[j] += bnb ? v * ((yr - bmu[j]) * brs[j]) : v * v;
       }
     }
   }
@@ -306,7 +318,8 @@ int device_cu_count() {
 }
 
 // mirrors the auto routing below: true when launch_conv(a, st) ends on a kernel whose epilogue can carry the fused
-// BatchNorm-backward sums (ConvArgs::bnb_*): conv_wino_kernel<NI>, conv_wino_x3_kernel, conv_patch16_kernel, conv_head_dgrad_kernel
+// BatchNorm-backward sums (ConvArgs::bnb_*): conv_wino_kernel<NI>, conv_wino_x3_kernel, conv_patch16_kernel, conv_head_dgrad_kernel,
+// conv_up2_dgrad_kernel, conv_igemm_kernel
 bool conv_routes_to_wino(const ConvArgs& a) {
   static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr;
   if (a.out_up) return (!no_up2 && conv_up2_dgrad_applicable(a)) || (a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a));
@@ -316,7 +329,10 @@ bool conv_routes_to_wino(const ConvArgs& a) {
   if (!no_head && conv_head_dgrad_applicable(a)) return true;
   if (wino_mode_of(a.wino) != 0 && conv_wino_applicable(a) && !conv_patch16_applicable(a))
     return a.prec == 1 || !conv_wino8_applicable(a);      // (the 8-wave variant has no fused BatchNorm-backward sums)
-  return conv_patch16_applicable(a);
+  if (conv_patch16_applicable(a)) return true;
+  if (conv_patch_applicable(a)) return false;             // (direct 3x3 kernels of Winograd mode 0: no bnb epilogue)
+  static const bool no_igemm_bnb = getenv("UWM_NO_IGEMM_BNB") != nullptr;
+  return !no_igemm_bnb;                                   // flattened implicit GEMM / stride-2 parity classes (conv_igemm.hip)
 }
 
 // tile configurations: {BM, BN}: 0:{128,128} 1:{128,64} 2:{128,32} 3:{128,16} 4:{64,64} 5:{64,128}

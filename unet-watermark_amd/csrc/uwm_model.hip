@@ -1037,8 +1037,10 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       if (bl.c3 >= 0) {                                      // Bottleneck tail: conv3 (1x1) <- relu(bn2(conv2))
         Src a2 = lazy_src(c, bl.c2, h, w);
         LCHK(run_wgrad(c, bl.c3, a2, nullptr, c.F(p.g[bl.c3]), h, w));
-        LCHK(run_dgrad(c, bl.c3, c.F(p.g[bl.c3]), h, w, h, w, c.F(p.g[bl.c2]), nullptr, a2.ptr, a2.scale, a2.shift));
-        LCHK(run_bn_bwd(c, bl.c2, c.F(p.g[bl.c2]), c.F(p.g[bl.c2]), npix));
+        bool c2_sums = false;                                // conv3's 1x1 dgrad (implicit GEMM epilogue) carries bn2's backward sums
+        LCHK(run_dgrad(c, bl.c3, c.F(p.g[bl.c3]), h, w, h, w, c.F(p.g[bl.c2]), nullptr, a2.ptr, a2.scale, a2.shift, nullptr,
+                       m->convs[bl.c2].bn, &c2_sums));
+        LCHK(run_bn_bwd(c, bl.c2, c.F(p.g[bl.c2]), c.F(p.g[bl.c2]), npix, c2_sums));
         hc1 = hin; wc1 = win;
       }
       Src a1 = lazy_src(c, bl.c1, hc1, wc1);
