@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
         }
         *(f4*)(a.out + o) = v;
+        if (a.bnb_y) yr = *(const f4*)(a.bnb_y + o);
         ps[j] += v; pq[j] += bnb ? v * ((yr - bmu[j]) * brs[j]) : v * v;
       }
     }
@@ -320,7 +321,15 @@ int device_cu_count() {
 // mirrors the auto routing below: true when launch_conv(a, st) ends on a kernel whose epilogue can carry the fused
 // BatchNorm-backward sums (ConvArgs::bnb_*): conv_wino_kernel<NI>, conv_wino_x3_kernel, conv_patch16_kernel, conv_head_dgrad_kernel,
 // conv_up2_dgrad_kernel, conv_igemm_kernel
+// (with a.bnb_y set: only the epilogues that read yhat from a separate tensor count — conv_wino_kernel<NI> and conv_igemm_kernel)
 bool conv_routes_to_wino(const ConvArgs& a) {
+  if (a.bnb_y) {
+    if (a.out_up || a.prec == 1) return false;
+    static const bool no_y = getenv("UWM_NO_BNB_Y") != nullptr;
+    if (no_y || conv_up2_applicable(a) || conv_head_applicable(a) || conv_head_dgrad_applicable(a) || conv_patch16_applicable(a)) return false;
+    if (wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)) return true;      // (launch_conv_wino skips the 8-wave variant when bnb_mean is set)
+    return !conv_patch_applicable(a);
+  }
   static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr;
   if (a.out_up) return (!no_up2 && conv_up2_dgrad_applicable(a)) || (a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a));
   static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;

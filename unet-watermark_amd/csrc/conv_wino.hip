@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvArgs a) {
             v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
           }
           *(f4*)(a.out + o) = v;
+          if (a.bnb_y) yr = *(const f4*)(a.bnb_y + o);
           ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
         }
       }
@@ -453,7 +454,7 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn) {
   if (a.out_up && ((a.Ho | a.Wo) & 1 || (a.up_c0 & 3) || a.up_c0 > a.Cout || a.addend || a.mask || a.bias || (a.ssum && !a.bnb_mean) ||
                    (a.up_c0 < a.Cout && !a.out) || bn == 8))
     return hipErrorInvalidValue;
-  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : a.mask) || a.up_accum || bn == 8)) return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum || bn == 8 || (a.out_up && a.bnb_y))) return hipErrorInvalidValue;
   if (bn == 8) return launch_conv_wino8(a, st);
   if (bn <= 0 && !a.bnb_mean && conv_wino8_applicable(a)) return launch_conv_wino8(a, st);
   if (bn <= 0) {

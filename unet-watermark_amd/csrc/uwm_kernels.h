@@ -63,6 +63,10 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   // (`mask` / `up_mask`), so it accumulates ssum += v (dbeta) and ssq += v * (mask_raw - mean) * rstd (dgamma) instead of the
   // forward's (v, v^2): bn_bwd_reduce's pass over both tensors disappears
   const float* bnb_mean; const float* bnb_rstd;
+  // bnb_y != nullptr: yhat is taken from THIS tensor (same [M][Cout] indexing as the output) instead of the mask tensor: the dgrad
+  // that writes the gradient wrt a residual block's OUTPUT (masked by that output) carries the sums of the block's last BatchNorm,
+  // whose raw input is a different tensor (conv_wino_kernel<NI> plain epilogue and conv_igemm_kernel only)
+  const float* bnb_y;
   FastDiv dv_ctot, dv_kw;
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
   double bytes;              // algorithmic HBM bytes of this launch: every operand read once + the output written once (profiling only)

@@ -124,6 +124,7 @@ struct uwm_model {
   int device = -1;                    // HIP device the bound arenas live on (uwm_bind)
   int nstages = 5;                    // backward stages = gradient buckets (head+decoder, then four encoder groups)
   bool hwq_warned = false;
+  std::vector<char> out_sums;        // per residual block: the BatchNorm-backward sums of its last BatchNorm were made by the dgrad that wrote its output gradient (run_dgrad bn_y)
 };
 
 static int add_bn(uwm_model* m, const std::string& name, int C, int stage, float eps = 0.f, float mom = 0.f) {
@@ -526,10 +527,11 @@ struct UpSplit { float* gprev; int C0; const float* pmask; const float* pscale; 
 // bn_fuse >= 0: the masked output of this dgrad is the gradient wrt the output of BatchNorm `bn_fuse`, whose raw input is the
 // ReLU mask the epilogue reads anyway: where the launch runs on a Winograd epilogue the BatchNorm-backward sums (dbeta,
 // dgamma partials, one of nrep replicas per workgroup) are accumulated there and *fused = true tells run_bn_bwd to skip
-// its reduce pass
+// its reduce pass.  bn_y: yhat comes from this tensor instead of the mask tensor (gradient wrt a residual block's output: masked by the
+// output, but the BatchNorm in question is the block's last one, whose raw input is bn_y)
 static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int Wo, int Hin, int Win, float* dx,
                             const float* addend, const float* mask, const float* mscale, const float* mshift,
-                            const UpSplit* us = nullptr, int bn_fuse = -1, bool* fused = nullptr) {
+                            const UpSplit* us = nullptr, int bn_fuse = -1, bool* fused = nullptr, const float* bn_y = nullptr) {
   const ConvL& cv = c.m->convs[ci];
   ConvArgs a; memset(&a, 0, sizeof(a));
   a.s0 = mk_src(dy, cv.CoutP, Ho, Wo); a.s1 = a.s0; a.C0 = cv.CoutP; a.Ctot = cv.CoutP;
@@ -546,7 +548,8 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
   if (fused) *fused = false;
   static const bool no_fuse = getenv("UWM_NO_BN_FUSE") != nullptr;
-  if (bn_fuse >= 0 && fused && !no_fuse && (us ? (us->pmask != nullptr && !us->accumulate) : (mask != nullptr)) && conv_routes_to_wino(a)) {
+  a.bnb_y = bn_y;                                  // (consulted by conv_routes_to_wino; cleared again when the sums are not fused)
+  if (bn_fuse >= 0 && fused && !no_fuse && (us ? (us->pmask != nullptr && !us->accumulate) : (mask != nullptr || bn_y != nullptr)) && conv_routes_to_wino(a)) {
     const BNL& b = c.m->bns[bn_fuse];
     if (b.C == (us ? us->C0 : cv.CinP)) {
       const float* f = c.F(b.f_off);
@@ -555,6 +558,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
       *fused = true;
     }
   }
+  if (!fused || !*fused) a.bnb_y = nullptr;
   return launch_conv(a, c.st);
 }
 
@@ -838,6 +842,8 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
   auto feat_mask = [&](const Src& f) -> const float* { return effnet ? nullptr : f.ptr; };
   Src f1 = effnet ? mk_src(c.F(p.stem_a), m->f1C, h1, w1) : lazy_src(c, m->stem, h1, w1);
 
+  std::vector<char>& out_sums = m->out_sums;
+  if (sb <= 0 || out_sums.size() != first_blk[3] + m->stages[3].size()) out_sums.assign(first_blk[3] + m->stages[3].size(), 0);
   if (sb <= 0 && se > 0) {
     HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
@@ -1031,7 +1037,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       const float* dz = c.F(p.gx[bi]);                       // masked grad wrt the block output
       const int lc = bl.last();
       const int hin = h * bl.stride, win = w * bl.stride;
-      LCHK(run_bn_bwd(c, lc, dz, c.F(p.g[lc]), npix));
+      LCHK(run_bn_bwd(c, lc, dz, c.F(p.g[lc]), npix, out_sums[bi] != 0));
       if (bl.cd >= 0) LCHK(run_bn_bwd(c, bl.cd, dz, c.F(p.g[bl.cd]), npix));
       int hc1 = h, wc1 = w;                                  // resolution of c1's output
       if (bl.c3 >= 0) {                                      // Bottleneck tail: conv3 (1x1) <- relu(bn2(conv2))
@@ -1065,7 +1071,14 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       } else {
         addend = dz;                                         // identity shortcut
       }
-      LCHK(run_dgrad(c, bl.c1, c.F(p.g[bl.c1]), hc1, wc1, hin, win, gin, addend, in_mask, nullptr, nullptr));
+      // gin is the (masked) gradient wrt the PREVIOUS block's output = the gradient wrt that block's last BatchNorm output: its
+      // backward sums ride in this epilogue, yhat read from that BatchNorm's raw input (run_dgrad bn_y)
+      int pbn = -1; const float* py = nullptr; size_t pbi = 0;
+      if (b > 0) { pbi = bi - 1; const int plc = m->stages[s][b - 1].last(); pbn = m->convs[plc].bn; py = c.F(p.y[plc]); }
+      else if (s > 0) { pbi = first_blk[s] - 1; const int plc = m->stages[s - 1].back().last(); pbn = m->convs[plc].bn; py = c.F(p.y[plc]); }
+      bool psums = false;
+      LCHK(run_dgrad(c, bl.c1, c.F(p.g[bl.c1]), hc1, wc1, hin, win, gin, addend, in_mask, nullptr, nullptr, nullptr, pbn, &psums, py));
+      if (pbn >= 0) out_sums[pbi] = psums ? 1 : 0;
     }
     if (s == 0) {
       // maxpool backward (+ decoder skip gradient for f1) -> stem BN backward -> stem wgrad
