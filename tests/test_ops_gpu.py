@@ -225,6 +225,24 @@ def test_conv1x1_shapes(cuda, shape):
     _conv_case(cuda, n, cin, cout, h, w, 1, 1, 0, lazy=True, seed=2)
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 64, 256, 16, 24),      # Bottleneck conv3 of layer1: K = 64 (two chunks per tile), two 128-channel tiles, 6 pixel tiles
+    (1, 256, 64, 16, 16),      # conv1: K = 256, one 64-channel tile
+    (3, 128, 96, 8, 12),       # ragged M (288 = 2.25 tiles), Cout 96 inside a 128-channel tile
+    (2, 96, 38, 16, 16),       # 38 real outputs in 40 padded channels: the pad must come out as exact zeros
+    (1, 32, 64, 16, 8),        # a single K chunk, M = 128 exactly
+    (5, 160, 192, 8, 8),       # MBConv-sized: K = 160 (five chunks), 2 + 1 channel tiles on the 64-wide config
+])
+@pytest.mark.parametrize("cfg", [-1, 864, 928])
+def test_conv_gemm_1x1(cuda, shape, cfg):
+    """conv_gemm.hip: 1x1 / stride-1 convs with Cin % 32 == 0 as a persistent LDS-DMA GEMM (a workgroup walks several tiles, the
+    statistics of one channel tile leave once, the lazy BatchNorm + ReLU is applied to the fragments after ds_read); auto route and
+    both tile widths, plain and lazy sources, BatchNorm statistics, zero padded channels."""
+    n, cin, cout, h, w = shape
+    _conv_case(cuda, n, cin, cout, h, w, 1, 1, 0, cfg=cfg)
+    _conv_case(cuda, n, cin, cout, h, w, 1, 1, 0, cfg=cfg, lazy=True, seed=5)
+
+
 @pytest.mark.parametrize("cin,cout,n,h,w", [(16, 1, 2, 32, 48), (16, 3, 1, 20, 36), (8, 1, 1, 9, 17), (32, 4, 2, 16, 16), (16, 2, 1, 64, 300)])
 def test_conv_head_streaming_kernel(cuda, cin, cout, n, h, w):
     """conv_head.hip (3x3 segmentation head, <= 4 classes): forced (cfg 500) and auto-routed, plain and lazy sources, bias,
@@ -301,6 +319,8 @@ def test_conv_upsample_concat(cuda):
     (2, 56, 336, 8, 16, 1, 1, 0),     # 1x1 expand with Kpad = 64: wgrad on the 128x64 tile (Kpad = 32 above: 128x32)
     (1, 160, 192, 8, 8, 1, 1, 0),     # Kpad = 160: three 64-column tiles instead of two 128-column ones
     (2, 48, 24, 16, 16, 1, 1, 0),     # 1x1 project with 24 outputs, Kpad = 64: wgrad on the 32x64 tile
+    (2, 64, 128, 16, 16, 1, 1, 0),    # 1x1 whose dgrad (K = 128 dY channels) runs on conv_gemm.hip with addend + mask
+    (1, 256, 64, 16, 24, 1, 1, 0),    # Bottleneck conv1: dgrad K = 64, 256 outputs (two channel tiles)
     (1, 144, 32, 8, 24, 1, 1, 0),     # Kpad = 160 under 32 outputs: the 32x64 / 32x128 tiles
     (1, 96, 24, 8, 8, 1, 1, 0),       # Kpad = 96
 ])

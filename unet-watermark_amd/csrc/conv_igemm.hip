@@ -354,6 +354,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
             (int)(cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)), a.flops * 1e-9);
   if (cfg == 700) return launch_conv_up2(a, st);
+  if (cfg >= 800 && cfg < 1000) return launch_conv_gemm(a, st, cfg - 800);
   if (cfg == 500) return launch_conv_head(a, st);
   if (cfg == 400) return launch_conv_wino_x3(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
@@ -383,6 +384,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   }
   if (cfg < 0 && conv_s2_dgrad_applicable(a))
     return a.Cout <= 64 ? launch_s2_dgrad<128, 64, 2, 2>(a, st, 1) : launch_s2_dgrad<128, 128, 2, 2>(a, st, 0);
+  if (cfg < 0 && conv_gemm_preferred(a)) return launch_conv_gemm(a, st, 0);      // 1x1 / stride 1, Cin % 32 == 0: persistent LDS-DMA GEMM
   if (cfg < 0) {
     const long tiles128 = (long)((a.M + 127) / 128);
     if (a.Cout <= 16) cfg = 3;

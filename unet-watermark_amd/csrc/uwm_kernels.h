@@ -104,7 +104,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 37 };   // 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 39 };   // 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -139,6 +139,9 @@ bool wgrad_c16_applicable(const WgradArgs& a);              // 16-channel full-r
 hipError_t launch_wgrad_c16(const WgradArgs& a, hipStream_t st);
 bool wgrad_up2_applicable(const WgradArgs& a);              // wgrad of conv_up2.hip's layer (nearest-x2 upsampled 32-channel input, 16 outputs)
 hipError_t launch_wgrad_up2(const WgradArgs& a, hipStream_t st);
+bool conv_gemm_applicable(const ConvArgs& a);             // 1x1 / stride-1 conv as a persistent LDS-DMA GEMM (conv_gemm.hip); force_cfg 800 (auto tile) / 864 / 928
+hipError_t launch_conv_gemm(const ConvArgs& a, hipStream_t st, int bn);
+bool conv_gemm_preferred(const ConvArgs& a);              // applicable AND enough tiles to fill the chip (else the implicit GEMM's 64x64 tiles)
 bool conv_up2_applicable(const ConvArgs& a);              // 3x3 over a nearest-x2 upsampled 32-channel input, 16 outputs (conv_up2.hip)
 hipError_t launch_conv_up2(const ConvArgs& a, hipStream_t st);
 bool conv_up2_dgrad_applicable(const ConvArgs& a);        // its dgrad wrt the low-resolution input, concat-split epilogue contract (ConvArgs::out_up)
