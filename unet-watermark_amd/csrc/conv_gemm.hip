@@ -32,7 +32,7 @@ __device__ __forceinline__ void gemm_glds16(const float* g, float* l) {      // 
 constexpr int kGM = 128;                         // pixels per tile
 
 template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a, int tilesM, int ntiles) {
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(const ConvArgs a, int tilesM, int ntiles) {
   constexpr int NI = BN / 32;                    // 16-channel MFMA tiles per wave (2 x 2 waves)
   constexpr int MI = 4;
   constexpr int XI = 4, WI = BN / 32;            // 1-KB LDS-DMA instructions per wave per chunk (X: 128 rows, W: BN rows)
@@ -235,10 +235,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvArgs a, int
   if (do_stats && stat_tn >= 0) flush_stats(stat_tn);
 }
 
-// few-pixel, many-channel layers (M = 4096 at 16^2 x bs16): 128-pixel tiles leave most workgroup slots empty; the 64x64 tiles of the
-// implicit GEMM fill the chip better there (measured 105 vs 146 us on 2048 -> 512 at 16^2)
+// launches with fewer 128x64 tiles than CUs stay on the implicit GEMM's 64x64 tiles
 bool conv_gemm_preferred(const ConvArgs& a) {
-  return conv_gemm_applicable(a) && (long)((a.M + kGM - 1) / kGM) * ((a.Cout + 63) / 64) >= (long)device_cu_count() * 3 / 2;
+  return conv_gemm_applicable(a) && (long)((a.M + kGM - 1) / kGM) * ((a.Cout + 63) / 64) >= (long)device_cu_count();
 }
 
 bool conv_gemm_applicable(const ConvArgs& a) {
@@ -253,7 +252,7 @@ static hipError_t launch_gemm(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesM = (a.M + kGM - 1) / kGM, tilesN = (a.Cout + BN - 1) / BN;
   const int ntiles = tilesM * tilesN;
   const size_t lds = (size_t)(2 * (kGM + BN) * 32 + 2 * BN * 2) * sizeof(float);
-  const int slots = 2 * device_cu_count();
+  const int slots = (BN == 64 ? 3 : 2) * device_cu_count();      // resident workgroups: 148 VGPRs / 48 KB LDS at BN = 64, 215 / 64 KB at 128
   const int nwg = ntiles < slots ? ntiles : slots;
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_gemm_kernel<BN>, lds); if (e != hipSuccess) return e; }
@@ -266,10 +265,13 @@ hipError_t launch_conv_gemm(const ConvArgs& a, hipStream_t st, int bn) {
   if (!conv_gemm_applicable(a)) return hipErrorInvalidValue;
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.bnb_y ? a.bnb_y : a.mask))) return hipErrorInvalidValue;
   if (bn <= 0) {
+    // 64-channel tiles run three workgroups per CU (148 VGPRs, 48 KB): better latency hiding for the short-K, HBM-bound layers
+    // and for launches with few tiles; 128-channel tiles read X half as often: the long-K layers with plenty of tiles
+    // (profiles/r02_*_time_1x1_r50.txt: cfg 864 vs 928 per shape)
     const int pad128 = ((a.Cout + 127) / 128) * 128, pad64 = ((a.Cout + 63) / 64) * 64;
-    bn = (a.Cout <= 64 || pad128 * 100 > pad64 * 115) ? 64 : 128;
     const long tilesM = (a.M + kGM - 1) / kGM;
-    if (bn == 128 && tilesM * (pad128 / 128) < 2L * device_cu_count()) bn = 64;      // fill the 2-per-CU slots first
+    bn = 128;
+    if (a.Cout <= 64 || pad128 * 100 > pad64 * 115 || a.Ctot <= 128 || tilesM * (pad128 / 128) < 4L * device_cu_count()) bn = 64;
   }
   return bn == 64 ? launch_gemm<64>(a, st, 38) : launch_gemm<128>(a, st, 37);
 }

@@ -694,7 +694,8 @@ const char* prof_class_name(int cls) {
       "wgrad_igemm_kernel<128,64,2,2>",  "wgrad_igemm_kernel<32,64,2,2>",  "wgrad_igemm_kernel<32,128,1,4>",
       "conv_head_kernel",               "conv_wino_x3_kernel",            "wgrad_c16_kernel",
       "wgrad_head_kernel",              "conv_up2_kernel",                "conv_up2_dgrad_kernel",
-      "wgrad_up2_kernel",               "conv_gemm_kernel<128>",          "conv_gemm_kernel<64>"};
+      "wgrad_up2_kernel",               "conv_gemm_kernel<128>",          "conv_gemm_kernel<64>",
+      "wgrad_gemm_kernel<128>",         "wgrad_gemm_kernel<64>"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

@@ -212,9 +212,11 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
     fprintf(stderr, "wgrad N=%d Ctot=%d(C0=%d) Cout=%d wrows=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d stride=%d wino=%d patch=%d gflop=%.2f\n", a0.N, a0.Ctot,
             a0.C0, a0.Cout, a0.wrows, a0.Ho, a0.Wo, a0.Hl, a0.Wl, a0.ntaps, a0.stride, (int)(wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)),
             (int)wgrad_patch_applicable(a0), a0.flops * 1e-9);
-  // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd
+  // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd, 4 = wgrad_gemm.hip wherever applicable
+  if ((a0.force_igemm & 0xff) == 4) return launch_wgrad_gemm(a0, st);
   static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr || getenv("UWM_NO_UP2_WGRAD") != nullptr;
   if ((a0.force_igemm & 0xff) == 0 && !no_up2 && wgrad_up2_applicable(a0)) return launch_wgrad_up2(a0, st);      // sub-pixel form of conv-after-upsample
+  if ((a0.force_igemm & 0xff) == 0 && wgrad_gemm_preferred(a0)) return launch_wgrad_gemm(a0, st);        // 1x1 / stride 1: persistent LDS-DMA GEMM, deterministic
   if ((a0.force_igemm & 0xff) == 0 && wgrad_c16_applicable(a0)) return launch_wgrad_c16(a0, st);      // 16-channel full-resolution layers, head
   if ((a0.force_igemm & 0xff) == 0 && wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
   if ((a0.force_igemm & 0xff) != 1 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);

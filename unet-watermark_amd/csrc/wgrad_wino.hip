@@ -545,6 +545,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st) {      // shared with wgrad_gemm.hip
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, part, nsplit, n4, dw);
+  return hipGetLastError();
+}
+
 constexpr int kMaxPartBlocks = 1024;          // workgroups of a split launch: bounds the partial-sum scratch
 size_t wgrad_wino_scratch_floats() { return (size_t)kMaxPartBlocks * 64 * kCW * 9; }
 
