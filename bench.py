@@ -340,6 +340,15 @@ def main():
                                 "note": "direct-convolution FLOPs of SURVEY.md 8(d) / the same duration; Winograd F(2x2,3x3) kernels "
                                         "execute 1/2.25 of them, so this figure is NOT a utilisation"},
                 "alone": alone,
+                # the next kernels by time in the step (the first three are within a few per cent of each other on the headline
+                # config, so which one is "dominant" can flip between runs): same definitions
+                "runners_up": [{"kernel": k["kernel"], "frac": round(k["mfma_tflops"] / P, 4), "avg_launch_us": k["avg_us"],
+                                "launches_per_step": k["launches_per_step"], "ms_per_step": k["ms_per_step"],
+                                "alone_frac": (round(ents_s[k["kernel"]]["mfma_tflops"] / P, 4)
+                                               if ents_s is not None and k["kernel"] in ents_s else None),
+                                "alone_avg_launch_us": (ents_s[k["kernel"]]["avg_us"]
+                                                        if ents_s is not None and k["kernel"] in ents_s else None)}
+                               for k in kernels[1:3]],
                 "step": {"mfma_tflops": round(tot_ex * 1e-9 / prof_steps / ms_step, 2),
                          "frac": round(tot_ex * 1e-9 / prof_steps / ms_step / P, 4),
                          "algorithmic_tflops": round(tot_fl * 1e-9 / prof_steps / ms_step, 2),

@@ -434,6 +434,36 @@ def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
     assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 128, 192), (3, 32, 64)])
+def test_wgrad_stem_compact_columns(cuda, n, h, w):
+    """wgrad_stem.hip: weight gradient of the 7x7 / stride-2 / pad-3 ResNet stem (3 input channels stored as 4) with compact GEMM
+    columns (147 real of 160) against autograd, bit-identical between two launches, pad channel / pad K of dW left untouched,
+    and equal (to rounding) to the flattened implicit GEMM it replaces."""
+    L = lib()
+    g = torch.Generator().manual_seed(51 + h)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(x, wt, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd, dyd = nhwc(x).to(cuda), nhwc(dy).to(cuda)
+    kpad = rup(49 * 4, 32)
+    s0 = src(xd)
+    outs = []
+    for force in (0, 0, 1):
+        dw = torch.zeros(64, kpad, device=cuda)
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h // 2, w // 2, 64, 64, kpad, 7, 7, 2, 3, P(dw), force, stream()))
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    got = unpack_w(outs[0], 64, 3, 7, 7)
+    tol = 3e-5 * max(1.0, float(wt.grad.abs().max()))
+    assert (got - wt.grad).abs().max() < tol
+    assert (outs[0] - outs[2]).abs().max() < tol
+    full = outs[0][:, :196].reshape(64, 49, 4)
+    assert (full[..., 3] == 0).all() and (outs[0][:, 196:] == 0).all()
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 16, 16), (1, 256, 64, 32, 32), (4, 96, 40, 16, 16), (1, 160, 192, 32, 32), (2, 32, 32, 16, 8)])
 @pytest.mark.parametrize("lazy", [False, True])
 def test_wgrad_gemm_1x1(cuda, n, cin, cout, h, w, lazy):

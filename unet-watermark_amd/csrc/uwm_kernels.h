@@ -104,7 +104,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 41 };   // 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 42 };   // 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -138,6 +138,8 @@ float* wgrad_op_scratch();                                  // the same, for the
 bool wgrad_c16_applicable(const WgradArgs& a);              // 16-channel full-resolution layers and the head (wgrad_c16.hip)
 hipError_t launch_wgrad_c16(const WgradArgs& a, hipStream_t st);
 hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st);      // dw += sum of nsplit full-size partial images, fixed order
+bool wgrad_stem_applicable(const WgradArgs& a);             // 7x7 / stride-2 / 3(4)-channel stem: compact-column wgrad (wgrad_stem.hip)
+hipError_t launch_wgrad_stem(const WgradArgs& a, hipStream_t st);
 bool wgrad_gemm_applicable(const WgradArgs& a);             // 1x1 / stride-1 weight gradient as a persistent LDS-DMA GEMM (wgrad_gemm.hip)
 hipError_t launch_wgrad_gemm(const WgradArgs& a, hipStream_t st);
 bool wgrad_gemm_preferred(const WgradArgs& a);            // applicable AND not a many-pixel / tiny-dW layer (those stay on wgrad_igemm)

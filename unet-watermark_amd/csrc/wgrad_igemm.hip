@@ -216,6 +216,7 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   if ((a0.force_igemm & 0xff) == 4) return launch_wgrad_gemm(a0, st);
   static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr || getenv("UWM_NO_UP2_WGRAD") != nullptr;
   if ((a0.force_igemm & 0xff) == 0 && !no_up2 && wgrad_up2_applicable(a0)) return launch_wgrad_up2(a0, st);      // sub-pixel form of conv-after-upsample
+  if ((a0.force_igemm & 0xff) == 0 && wgrad_stem_applicable(a0)) return launch_wgrad_stem(a0, st);         // the ResNet stem: compact K = 147
   if ((a0.force_igemm & 0xff) == 0 && wgrad_gemm_preferred(a0)) return launch_wgrad_gemm(a0, st);        // 1x1 / stride 1: persistent LDS-DMA GEMM, deterministic
   if ((a0.force_igemm & 0xff) == 0 && wgrad_c16_applicable(a0)) return launch_wgrad_c16(a0, st);      // 16-channel full-resolution layers, head
   if ((a0.force_igemm & 0xff) == 0 && wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
