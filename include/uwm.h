@@ -244,13 +244,17 @@ typedef struct {
  * stats (2*Cout doubles: sum, sumsq; pre-zeroed) may be NULL.
  * cfg: -1 = the library's routing; 0..5 implicit-GEMM tile configs; 100+BN direct patch kernel; 200 16-channel patch
  * kernel; 300 (+BN, 308 = 8-wave) Winograd F(2x2,3x3); 400 Winograd in bf16x3 arithmetic; 500 segmentation-head streaming
- * kernel (tests / timing). */
+ * kernel; 700 sub-pixel kernel for a 3x3 over a nearest-x2 upsampled 32-channel source with 16 outputs (conv_up2.hip);
+ * 800 (+64 | +128 = channel tile) persistent LDS-DMA GEMM for 1x1 / stride-1 layers with Cin % 32 == 0 (conv_gemm.hip)
+ * (tests / timing). */
 int  uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
                  int pad, int N, int Cout, const float* bias, float* y, double* stats, int cfg, uwm_stream stream);
 /* dx[N][H][W][Cin] = conv_transpose(dy[N][Ho][Wo][Cout], wd) (+addend, *relu-mask) ; wd [Cin][KpadD] */
 int  uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float* wd, int Cin, int KpadD, int kh, int kw,
                   int stride, int pad, int H, int W, const float* addend, const float* mask, const float* mscale,
                   const float* mshift, float* dx, uwm_stream stream);
+/* force_igemm: 0 = the library's routing (Winograd-domain / sub-pixel / 16-channel / stem / 1x1-GEMM kernels where they apply);
+ * 1 = flattened implicit GEMM only; 2 = no Winograd; 4 = wgrad_gemm.hip wherever applicable (tests / timing) */
 int  uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, int Ho, int Wo, int Cout, int wrows,
                   int Kpad, int kh, int kw, int stride, int pad, float* dw, int force_igemm, uwm_stream stream);
 int  uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,
