@@ -408,7 +408,8 @@ def test_wgrad_c16_and_head(cuda, cout, n, h, w):
     assert (runs[0][:, 9 * cin:] == 0).all()
 
 
-@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 32, 32), (32, 32, 64)])
+@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 32, 32), (32, 32, 64),
+                                        (64, 48, 32), (32, 24, 64), (64, 56, 128)])      # channel tails of the EfficientNet decoder concats (Ctot % 32 != 0)
 def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
     L = lib()
     g = torch.Generator().manual_seed(7)
@@ -432,6 +433,7 @@ def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
     torch.cuda.synchronize()
     got = unpack_w(dw.cpu(), cout, c0 + c1, 3, 3)
     assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+    assert (dw.cpu()[:, 9 * (c0 + c1):] == 0).all()           # K padding of dW stays exactly zero
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 128, 192), (3, 32, 64)])

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(const WgradArgs a) 
   const int li = lane & 15, lq = lane >> 4;
   const int wca = (wave >> 1) * NCA, wcb = wave & 1;
 
-  const int nchunk = a.Ctot / kCW;
+  const int nchunk = (a.Ctot + kCW - 1) / kCW;      // (the last chunk of the second source may be partial: Ctot % 8 == 0)
   const int tilesA = a.Cout / TA;
   const int tilesW = a.Wo / kSW, tilesH = a.Ho / kSH;
   const int nstages = a.N * tilesH * tilesW;
@@ -305,7 +305,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(const WgradArgs a) 
   const int sC = first ? a.s0.C : a.s1.C, sH = first ? a.s0.H : a.s1.H, sW = first ? a.s0.W : a.s1.W;
   const int sup = first ? a.s0.up : a.s1.up;
   const int trelu = first ? a.s0.relu : a.s1.relu;
-  const int cl = (first ? cc * kCW : cc * kCW - a.C0) + chu * 4;
+  const int cl_raw = (first ? cc * kCW : cc * kCW - a.C0) + chu * 4;
+  // channel tail (Ctot % 32 != 0: EfficientNet decoder concats 64 + 48, 256 + 56): units past the source's channel count are
+  // read from its last unit (a valid address) and stored as zeros
+  const bool cvalid = cl_raw + 4 <= sC;
+  const int cl = cvalid ? cl_raw : sC - 4;
   const bool thas = ssc != nullptr;
   f4 tsc = {1.f, 1.f, 1.f, 1.f}, tsh = {0.f, 0.f, 0.f, 0.f};
   if (thas) { tsc = *(const f4*)(ssc + cl); tsh = *(const f4*)(ssh + cl); }
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(const WgradArgs a) 
         v = v * tsc + tsh;
         if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
-      if ((pinv >> (4 * rd)) & 0xFu) v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (((pinv >> (4 * rd)) & 0xFu) || !cvalid) v = (f4){0.f, 0.f, 0.f, 0.f};
       if (ppos[rd] >= 0) *(f4*)(ps + ppos[rd]) = v;
     }
   };
@@ -515,11 +519,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino2_kernel(const WgradArgs a) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = a0 + (wca + q) * 16 + lq * 4 + e;
-          if (row < a.wrows) {
+          if (row < a.wrows && cc * kCW + wcb * 16 + li < a.Ctot) {
             float* p = dst + (size_t)row * a.Kpad + (r * 3 + s_) * a.Ctot + cc * kCW + wcb * 16 + li;
             *p = direct ? *p + w3[s_][e] : w3[s_][e];
           }
         }
+    }
+  }
+  // K padding of a partial image (Kpad > 9 * Ctot only when Ctot % 32 != 0): the reduce adds whole images, so it must read zeros there
+  if (!direct && cc == nchunk - 1 && a.Kpad > 9 * a.Ctot) {
+    const int padw = a.Kpad - 9 * a.Ctot;
+    for (int i = tid; i < TA * padw; i += 256) {
+      const int row = a0 + i / padw;
+      if (row < a.wrows) dst[(size_t)row * a.Kpad + 9 * a.Ctot + i % padw] = 0.f;
     }
   }
 }
@@ -585,8 +597,11 @@ static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nbl
 
 bool wgrad_wino_applicable(const WgradArgs& a) {
   const int TA = a.Cout >= 64 ? 64 : a.Cout;
-  return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
-         (TA == 64 || TA == 32 || TA == 16) && a.Cout % TA == 0 && a.wrows <= a.Cout && a.Kpad == 9 * a.Ctot &&
+  // channel tail (wgrad_wino2 only, TA >= 32): Ctot % 8 == 0 with the concat boundary on a 32-channel chunk
+  static const bool v1 = getenv("UWM_WGRAD_V1") != nullptr;
+  const bool tail_ok = TA >= 32 && !v1 && (a.Ctot & 7) == 0 && (a.Ctot - a.C0 == 0 || (a.Ctot - a.C0) >= 4);
+  return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && ((a.Ctot & 31) == 0 || tail_ok) && ((a.C0 & 31) == 0 || (tail_ok && a.C0 == a.Ctot)) &&
+         (TA == 64 || TA == 32 || TA == 16) && a.Cout % TA == 0 && a.wrows <= a.Cout && a.Kpad >= 9 * a.Ctot && a.Kpad < 9 * a.Ctot + 32 &&
          a.Hl == a.Ho && a.Wl == a.Wo && (a.Ho % kSH) == 0 && (a.Wo % kSW) == 0;
 }
 
@@ -596,7 +611,7 @@ hipError_t launch_wgrad_wino(const WgradArgs& a0, hipStream_t st) {
   int TA = a.Cout >= 64 ? 64 : a.Cout;
   static const int force_ta = getenv("UWM_WW_TA") ? atoi(getenv("UWM_WW_TA")) : 0;      // experiments
   if (force_ta && TA > force_ta && a.Cout % force_ta == 0) TA = force_ta;
-  const int nchunk = a.Ctot / kCW, tilesA = a.Cout / TA;
+  const int nchunk = (a.Ctot + kCW - 1) / kCW, tilesA = a.Cout / TA;
   const int nstages = a.N * (a.Ho / kSH) * (a.Wo / kSW);
   // cost model: rounds x (stages per workgroup + epilogue worth E stages); a split launch is capped at kMaxPartBlocks
   // workgroups (the partial-sum scratch) and, from 8 splits on, uses a multiple of 8 of them (one XCD per split)
