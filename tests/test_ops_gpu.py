@@ -232,6 +232,9 @@ def test_conv1x1_shapes(cuda, shape):
     (2, 96, 38, 16, 16),       # 38 real outputs in 40 padded channels: the pad must come out as exact zeros
     (1, 32, 64, 16, 8),        # a single K chunk, M = 128 exactly
     (5, 160, 192, 8, 8),       # MBConv-sized: K = 160 (five chunks), 2 + 1 channel tiles on the 64-wide config
+    (2, 24, 144, 16, 24),      # K = 24: one PARTIAL chunk (clamped duplicate units of X against W's zero padding)
+    (1, 144, 40, 16, 24),      # K = 144 = 4.5 chunks, 40 outputs
+    (2, 56, 336, 16, 16),      # K = 56
 ])
 @pytest.mark.parametrize("cfg", [-1, 864, 928])
 def test_conv_gemm_1x1(cuda, shape, cfg):
@@ -466,7 +469,8 @@ def test_wgrad_stem_compact_columns(cuda, n, h, w):
     assert (full[..., 3] == 0).all() and (outs[0][:, 196:] == 0).all()
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 16, 16), (1, 256, 64, 32, 32), (4, 96, 40, 16, 16), (1, 160, 192, 32, 32), (2, 32, 32, 16, 8)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 16, 16), (1, 256, 64, 32, 32), (4, 96, 40, 16, 16), (1, 160, 192, 32, 32), (2, 32, 32, 16, 8),
+                                            (2, 56, 336, 16, 16), (1, 144, 32, 32, 32), (4, 24, 144, 16, 16)])      # Cin % 32 != 0: dW pad columns stay zero
 @pytest.mark.parametrize("lazy", [False, True])
 def test_wgrad_gemm_1x1(cuda, n, cin, cout, h, w, lazy):
     """wgrad_gemm.hip: weight gradient of the 1x1 / stride-1 convs (Cin % 32 == 0) as an LDS-DMA GEMM over the pixels with per-split
@@ -495,6 +499,7 @@ def test_wgrad_gemm_1x1(cuda, n, cin, cout, h, w, lazy):
     assert torch.equal(outs[0], outs[1])
     got = unpack_w(outs[0], cout, cin, 1, 1)
     assert (got - wt.grad).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+    assert (outs[0][:, cin:] == 0).all()
     # accumulate semantics: a second launch into the same buffer doubles it
     dw = outs[0].to(cuda).clone()
     L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h, w, coutp, cout, kpad, 1, 1, 1, 0, P(dw), 4, stream()))

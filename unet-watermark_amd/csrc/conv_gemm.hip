@@ -1,6 +1,6 @@
 // 1x1 / stride-1 convolution (forward and dgrad) as a persistent, LDS-DMA-fed GEMM for gfx950 (v_mfma_f32_16x16x4_f32):
-// the Bottleneck 1x1s of resnet50 and the MBConv expand / project convs of EfficientNet whose input channel count is a
-// multiple of 32.
+// the Bottleneck 1x1s of resnet50 and the MBConv expand / project convs of EfficientNet (input channels a multiple of 4: a
+// partial last K chunk reads clamped, duplicate units of X against the zero padding of W's rows).
 //
 //   D[pixel][co] = sum_c X[pixel][c] * W[co][c]        X: NHWC rows = pixels (no gather: a 1x1 / stride-1 conv IS a GEMM)
 //
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = lane & 15, lq = lane >> 4;
-  const int nk = a.Ctot >> 5;
+  const int nk = (a.Ctot + 31) >> 5;              // a partial last chunk reads clamped (valid, duplicate) units against zero weight columns
+  const int xunits = a.Ctot >> 2;
   const int ldx = a.s0.C;
 
   // contiguous, balanced range of tiles for this workgroup; tile t = tn * tilesM + tm (pixel tiles fastest: the channel tile's
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
       const int row = (i * 4 + wave) * 8 + urow;
       const int u = upos ^ ((row >> 1) & 7);
       const int m = min(m0 + row, a.M - 1);                      // rows past M: a valid duplicate, discarded by the epilogue
-      gemm_glds16(a.s0.ptr + (size_t)m * ldx + kc * 32 + u * 4, xs + (i * 4 + wave) * 256);
+      gemm_glds16(a.s0.ptr + (size_t)m * ldx + min(kc * 8 + u, xunits - 1) * 4, xs + (i * 4 + wave) * 256);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
   auto lazy_load = [&](int kc, int par) {
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
-      const int k = kc * 32 + (k16 * 4 + lq) * 4;
+      const int k = min(kc * 32 + (k16 * 4 + lq) * 4, a.Ctot - 4);
       lsc[par][k16] = *(const f4*)(a.s0.scale + k); lsh[par][k16] = *(const f4*)(a.s0.shift + k);
     }
   };
@@ -235,15 +236,20 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
   if (do_stats && stat_tn >= 0) flush_stats(stat_tn);
 }
 
-// launches with fewer 128x64 tiles than CUs stay on the implicit GEMM's 64x64 tiles
+// Where the implicit GEMM stays ahead (profiles/r02_*_time_1x1*.txt, both kernels per shape): 32 output channels (half of a
+// 64-channel tile wasted: 69 vs 52 us on 192 -> 32 at 256^2), and launches that fill fewer than two 128x64 tiles per CU unless K is
+// long enough for the pipeline to pay anyway (2048 -> 512 at 16^2: 87 vs 106 us; 960 -> 160 at 64^2: 76 vs 72)
 bool conv_gemm_preferred(const ConvArgs& a) {
-  return conv_gemm_applicable(a) && (long)((a.M + kGM - 1) / kGM) * ((a.Cout + 63) / 64) >= (long)device_cu_count();
+  if (!conv_gemm_applicable(a) || a.Cout < 48) return false;
+  const long tiles64 = (long)((a.M + kGM - 1) / kGM) * ((a.Cout + 63) / 64);
+  const long cus = device_cu_count();
+  return tiles64 >= 2 * cus || (a.Ctot >= 1024 && tiles64 >= cus);
 }
 
 bool conv_gemm_applicable(const ConvArgs& a) {
   static const bool off = getenv("UWM_NO_CONV_GEMM") != nullptr;
   return !off && a.ntaps == 1 && a.kw == 1 && a.smul == 1 && a.sdiv == 1 && a.off == 0 && a.s0.up == 0 && a.C0 == a.Ctot && a.s0.C == a.Ctot &&
-         (a.Ctot & 31) == 0 && a.Kpad >= a.Ctot && a.Hl == a.Ho && a.Wl == a.Wo && a.s0.H == a.Ho && a.s0.W == a.Wo && !a.out_up &&
+         (a.Ctot & 3) == 0 && a.Ctot >= 16 && a.Kpad >= ((a.Ctot + 31) & ~31) && a.Hl == a.Ho && a.Wl == a.Wo && a.s0.H == a.Ho && a.s0.W == a.Wo && !a.out_up &&
          a.M >= kGM && a.Cout >= 32 && (a.Cout & 3) == 0 && a.wrows >= 1 && a.prec == 0;
 }
 

@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256, (TA + TB <= 128 ? 4 : (TA + TB <= 192 ? 3 : 2)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int co = a0 + (wa * MI + i) * 16 + lq * 4 + e;
-        if (co < a.wrows && c < a.Ctot) {
+        if (co < a.wrows && c < a.Kpad) {                // columns in [Ctot, Kpad): zeros in a partial image (the reduce adds whole images), untouched in dW
           float* const d = o + (size_t)co * a.Kpad + c;
-          if (split_stride) *d = acc[i][j][e]; else *d += acc[i][j][e];
+          if (split_stride) *d = c < a.Ctot ? acc[i][j][e] : 0.f; else if (c < a.Ctot) *d += acc[i][j][e];
         }
       }
     }
@@ -146,14 +146,14 @@ bool wgrad_gemm_preferred(const WgradArgs& a) {
 bool wgrad_gemm_applicable(const WgradArgs& a) {
   static const bool off = getenv("UWM_NO_WGRAD_GEMM") != nullptr;
   return !off && a.ntaps == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.s0.up == 0 && a.C0 == a.Ctot && a.s0.C == a.Ctot &&
-         (a.Ctot & 31) == 0 && a.Kpad == a.Ctot && (a.Cout & 3) == 0 && a.Cout >= 32 && a.Ctot >= 32 && (a.M & 31) == 0 && a.M >= 256 &&
+         (a.Ctot & 3) == 0 && a.Kpad == ((a.Ctot + 31) & ~31) && (a.Cout & 3) == 0 && a.Cout >= 32 && a.Ctot >= 16 && (a.M & 31) == 0 && a.M >= 256 &&
          a.Hl == a.Ho && a.Wl == a.Wo && a.s0.H == a.Ho && a.s0.W == a.Wo;
 }
 
 template <int TA, int TB>
 static hipError_t launch_wg(const WgradArgs& a0, hipStream_t st, int cls) {
   WgradArgs a = a0;
-  const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Ctot + TB - 1) / TB;
+  const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Kpad + TB - 1) / TB;      // (Kpad, not Ctot: the pad columns of the partial images must be written)
   const int ntiles = tilesA * tilesB;
   // pixel splits: fill 2 workgroups per CU, at least 8 stages (256 pixels) per split, bounded by the partial-sum scratch
   const int slots = (TA + TB <= 128 ? 4 : (TA + TB <= 192 ? 3 : 2)) * device_cu_count();      // resident workgroups by LDS (32 / 48 / 64 KB)
@@ -179,7 +179,7 @@ static hipError_t launch_wg(const WgradArgs& a0, hipStream_t st, int cls) {
 
 hipError_t launch_wgrad_gemm(const WgradArgs& a, hipStream_t st) {
   if (!wgrad_gemm_applicable(a)) return hipErrorInvalidValue;
-  if (a.Ctot <= 64) return a.wrows <= 64 ? launch_wg<64, 64>(a, st, 40) : launch_wg<128, 64>(a, st, 39);
+  if (a.Kpad <= 64) return a.wrows <= 64 ? launch_wg<64, 64>(a, st, 40) : launch_wg<128, 64>(a, st, 39);
   return a.wrows <= 64 ? launch_wg<64, 128>(a, st, 40) : launch_wg<128, 128>(a, st, 39);
 }
 
