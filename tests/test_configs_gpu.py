@@ -157,3 +157,76 @@ def test_config5_bs64_512_hipgraph(cuda):
     differ = mask != ref_mask
     assert not bool((differ & ((o_ref[:, 0] - thr).abs() > LOGIT_TOL)).any())
     assert float(differ.float().mean()) < 1e-4
+
+
+LARGE_DEC = (1024, 512, 256, 128, 64)
+
+
+def test_f3_large_yaml(cuda):
+    """The reference's large configuration AS WRITTEN (/root/reference/src/configs/unet_watermark_large.yaml:5-19,36):
+    UnetPlusPlus + resnet50 + DECODER_CHANNELS [1024, 512, 256, 128, 64] + IMG_SIZE 1024 + BATCH_SIZE 8.
+    (a) oracle parity at 2x3x128x128 — what the CPU oracle finishes in seconds: logits <= 1e-3, Dice 1e-5, per-tensor
+    gradient bars of the resnet50 tests; (b) the full 8x3x1024x1024 step as properties: finite, staged == whole backward,
+    the loss falls over Trainer steps with the YAML's GRADIENT_CLIP, 32-bit pixel-offset guard not tripped."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    from unet_watermark_amd.train import Trainer
+    from unet_watermark_amd import _lib as L
+    ref = O.build("resnet50", seed=3, arch="UnetPlusPlus", decoder_channels=LARGE_DEC)
+    m = U.UnetPlusPlus("resnet50", decoder_channels=LARGE_DEC).to(cuda)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    assert m.num_parameters() == sum(p.numel() for p in ref.parameters()) == 92973185
+    m.load_state_dict(ref.state_dict())
+    m.train(); ref.train()
+    x, t = O.synthetic_batch(2, 128, 128, seed=5)
+    o_ref = ref(x); l_ref = O.DiceLoss(smooth=1e-5)(o_ref, t.unsqueeze(1)); l_ref.backward()
+    o = m(x.to(cuda)); l = U.DiceLoss(mode="binary", smooth=1e-5)(o, t.unsqueeze(1).to(cuda)); l.backward()
+    err = float((o.detach().cpu() - o_ref.detach()).abs().max())
+    assert err < LOGIT_TOL, err
+    assert abs(float(l.detach()) - float(l_ref.detach())) < 1e-5
+    cos, l2 = _grad_cos_l2(m, ref)
+    assert cos > 0.9975 and l2 < 7e-2, (cos, l2)          # the resnet50 bars (tests/test_model_gpu.py: two fp32 runs of this net differ by 2-4.5 %)
+    del ref, o_ref, l_ref
+    # (b) the YAML's own size
+    need = L.lib().uwm_workspace_bytes(m._h, 8, 1024, 1024, 1)
+    assert need > 0, L.lib().uwm_last_error().decode()     # 32-bit pixel-offset guard (check_shape) not tripped
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(8, 3, 1024, 1024, generator=g).to(cuda)
+    t = torch.zeros(8, 1024, 1024, dtype=torch.uint8)
+    for i in range(8):
+        t[i, 100 * i: 100 * i + 300, 64 * i: 64 * i + 400] = 1
+    t = t.to(cuda)
+
+    def run(staged):
+        logits = m._forward_raw(x, training=True)
+        dl = torch.zeros_like(logits)
+        dl[..., 0] = torch.randn(logits.shape[:-1], device=cuda, generator=torch.Generator(device="cuda").manual_seed(1)) * 1e-4
+        if staged:
+            for k in range(len(m.stages)):
+                m._backward_raw(dl, k, k + 1)
+        else:
+            m._backward_raw(dl)
+        torch.cuda.synchronize()
+        return logits, m.flat_grads().clone()
+
+    (lg, a), (_, b), (_, c) = run(False), run(False), run(True)
+    assert lg.shape == (8, 1024, 1024, 4)
+    assert torch.isfinite(lg).all() and torch.isfinite(a).all() and float(a.abs().max()) > 0
+    checked = 0
+    for name, kind, arena, off, shp, strd in m._infos:
+        if arena != 0:
+            continue
+        va, vb, vc = (g_.as_strided(shp, strd, off).double() for g_ in (a, b, c))
+        if float(va.norm()) == 0:
+            continue
+        noise = float((va - vb).norm() / va.norm()); diff = float((vc - va).norm() / va.norm())
+        assert diff <= max(1e-5, 10 * noise), f"{name}: staged vs whole {diff:.2e}, run-to-run {noise:.2e}"
+        checked += 1
+    assert checked > 200
+    del a, b, c, lg
+    tr = Trainer(m, w_dice=1.0, w_bce=0.0, lr=1e-3, weight_decay=1e-4, max_grad_norm=1.0)     # LOSS.NAME DiceLoss, GRADIENT_CLIP 1.0
+    l0 = float(tr.step(x, t)[0])
+    for _ in range(3):
+        l1 = float(tr.step(x, t)[0])
+    assert l1 == l1 and l1 < l0, (l0, l1)
+    assert torch.isfinite(m.flat_parameters()).all()

@@ -500,9 +500,11 @@ def test_cli_train_on_synthetic_learns(cuda, tmp_path):
     from unet_watermark_amd import cli
     hist = cli.main(["train", "--epochs", "3", "--batch-size", "4", "--lr", "0.002", "--no-early-stopping",
                      "--synthetic", "32", "--img-size", "64", "--encoder", "resnet18", "--workers", "0",
-                     "--model-save-path", str(tmp_path / "best.pth")])
+                     "--model-save-path", str(tmp_path / "best.pth"), "--checkpoint-dir", str(tmp_path / "ck")])
     assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
     from unet_watermark_amd.checkpoint import load_checkpoint
+    fin = load_checkpoint(str(tmp_path / "ck" / "final_model_epoch_003.pth"))       # /root/reference/src/train.py:467-485
+    assert fin["is_final"] is True and fin["epoch"] == 3 and fin["optimizer_state_dict"]["state"] and "best_val_loss" in fin
     ck = load_checkpoint(str(tmp_path / "best.pth"))
     assert "encoder.conv1.weight" in ck["model_state_dict"] and ck["config"]["MODEL"]["ENCODER_NAME"] == "resnet18"
 
@@ -546,6 +548,14 @@ def test_bench_ddp_path_single_rank_rccl(cuda):
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads(ddp.stdout.strip().splitlines()[-1]); b = json.loads(one.stdout.strip().splitlines()[-1])
     assert a["config"]["grad_allreduce"].startswith("rccl") and b["config"]["grad_allreduce"] == "none"
+    # the data-parallel run validates itself during warm-up (bucket checksums across ranks, bucketed == single all-reduce,
+    # parameters after step 1) and says how many RCCL ranks it really had
+    assert a["rccl_ranks"] == 1 and b["rccl_ranks"] == 0 and b["ddp_check"] is None
+    ck = a["ddp_check"]
+    assert ck["ranks"] == 1 and len(ck["buckets"]) == 5 and ck["params_bit_identical_after_step1"]
+    assert all(r["bit_identical_across_ranks"] and r["max_abs"] > 0 for r in ck["buckets"])
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr          # --gpus N without N ranks fails loudly
     assert abs(a["loss"] - b["loss"]) < 1e-4 and a["value"] > 0
 
 
@@ -909,3 +919,63 @@ def test_backward_is_bit_reproducible(cuda, arch):
             assert d <= 1e-5 * nrm + 1e-12, f"{name}: {d / max(nrm, 1e-30):.2e}"
             loose += 1
     assert exact >= 40 and loose > 0
+
+
+def test_fused_sgd_resumes_torch_sgd_momentum(cuda):
+    """A torch.optim.SGD (= reference, /root/reference/src/train.py:272-278) checkpoint resumes on FusedSGD WITH its momentum:
+    torch's SGD state has 'momentum_buffer' but no 'step'; the loaded buffer must not be taken for an uninitialised one
+    (the kernel's first step overwrites the buffer with the raw gradient).  torch SGD takes 2 steps, FusedSGD loads that
+    state, each takes one more step on the same gradient: same parameters."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd.train import FusedSGD
+    torch.manual_seed(5)
+    m = U.Unet("resnet18").to(cuda)
+    twin = U.Unet("resnet18").to(cuda)
+    twin.load_state_dict(m.state_dict())
+    topt = torch.optim.SGD(twin.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(2):
+        for p in twin.parameters():
+            p.grad = torch.randn(p.shape, device=cuda, generator=gen)
+        topt.step()
+    m.load_state_dict(twin.state_dict())
+    fopt = FusedSGD(m, lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    fopt.load_state_dict(topt.state_dict())
+    assert fopt._step >= 1
+    m._ensure_bound()
+    for p, gv in zip(twin.parameters(), m._grad_views):
+        gnew = torch.randn(p.shape, device=cuda, generator=gen)
+        p.grad = gnew.clone(); gv.copy_(gnew)
+    topt.step(); fopt.step()
+    torch.cuda.synchronize()
+    for (n1, a), (_, b) in zip(m.named_parameters(), twin.named_parameters()):
+        assert (a - b).abs().max() < 2e-6, n1
+
+
+def test_fused_optimizer_releases_p_grad_with_its_lifetime(cuda):
+    """While a fused flat optimizer lives, autograd backward leaves p.grad unset (the arena is consumed directly); once it
+    is closed or dropped, the SAME model feeds torch.optim / clip_grad_norm_ again (p.grad populated)."""
+    import gc
+    import unet_watermark_amd as U
+    from unet_watermark_amd.train import FusedAdam
+    from oracle import unet_oracle as O
+    m = U.Unet("resnet18").to(cuda)
+    x, t = O.synthetic_batch(2, 64, 64, seed=3)
+    crit = U.DiceLoss(mode="binary", smooth=1e-5)
+
+    def bwd():
+        for p in m.parameters():
+            p.grad = None
+        crit(m(x.to(cuda)), t.unsqueeze(1).to(cuda)).backward()
+        return all(p.grad is not None for p in m.parameters())
+
+    assert bwd()
+    opt = FusedAdam(m)
+    assert not bwd() and m._arena_grads_only
+    opt.close()
+    assert bwd() and not m._arena_grads_only
+    opt2 = FusedAdam(m)
+    assert not bwd()
+    del opt2, opt; gc.collect()
+    assert bwd()
+    assert float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)) > 0

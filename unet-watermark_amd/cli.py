@@ -230,6 +230,13 @@ def train_command(args):
             if rank == 0:
                 print(json.dumps({"early_stop": epoch + 1, "best_val_loss": stopper.best_loss}), flush=True)
             break
+    # final model (/root/reference/src/train.py:467-485): weights as they stand after the loop — i.e. the RESTORED best weights
+    # after an early stop — with the optimizer / scheduler state and is_final=True
+    if rank == 0 and hist:
+        last = hist[-1]
+        save_checkpoint(os.path.join(cfg.TRAIN.CHECKPOINT_DIR, f"final_model_epoch_{last['epoch']:03d}.pth"), model,
+                        last["epoch"], last["val_loss"], last["val_metrics"], cfg, optimizer=trainer.opt, scheduler=sched,
+                        train_loss=last["train_loss"], train_metrics={}, best_val_loss=best, is_final=True)
     if own_group:
         dist.destroy_process_group()
     return hist

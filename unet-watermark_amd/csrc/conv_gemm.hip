@@ -247,7 +247,7 @@ bool conv_gemm_preferred(const ConvArgs& a) {
 }
 
 bool conv_gemm_applicable(const ConvArgs& a) {
-  static const bool off = getenv("UWM_NO_CONV_GEMM") != nullptr;
+  static const bool off = dbg_flag("UWM_NO_CONV_GEMM");
   return !off && a.ntaps == 1 && a.kw == 1 && a.smul == 1 && a.sdiv == 1 && a.off == 0 && a.s0.up == 0 && a.C0 == a.Ctot && a.s0.C == a.Ctot &&
          (a.Ctot & 3) == 0 && a.Ctot >= 16 && a.Kpad >= ((a.Ctot + 31) & ~31) && a.Hl == a.Ho && a.Wl == a.Wo && a.s0.H == a.Ho && a.s0.W == a.Wo && !a.out_up &&
          a.M >= kGM && a.Cout >= 32 && (a.Cout & 3) == 0 && a.wrows >= 1 && a.prec == 0;

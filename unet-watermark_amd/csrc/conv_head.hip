@@ -218,7 +218,7 @@ static hipError_t launch_head(const ConvArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_conv_head(const ConvArgs& a, hipStream_t st) {
-  if (!conv_head_applicable(a)) return hipErrorInvalidValue;
+  if (!conv_head_applicable(a) || a.bnb_mean) return hipErrorInvalidValue;      // (the forward head has no BatchNorm-backward epilogue)
   switch (a.Ctot) {
     case 8: return launch_head<2>(a, st);
     case 16: return launch_head<4>(a, st);

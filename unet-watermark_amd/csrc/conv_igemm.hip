@@ -322,17 +322,17 @@ int device_cu_count() {
 // BatchNorm-backward sums (ConvArgs::bnb_*): conv_wino_kernel<NI>, conv_wino_x3_kernel, conv_patch16_kernel, conv_head_dgrad_kernel,
 // conv_up2_dgrad_kernel, conv_igemm_kernel
 // (with a.bnb_y set: only the epilogues that read yhat from a separate tensor count — conv_wino_kernel<NI> and conv_igemm_kernel)
-bool conv_routes_to_wino(const ConvArgs& a) {
+bool conv_epilogue_carries_bnb(const ConvArgs& a) {
   if (a.bnb_y) {
     if (a.out_up || a.prec == 1) return false;
-    static const bool no_y = getenv("UWM_NO_BNB_Y") != nullptr;
+    static const bool no_y = dbg_flag("UWM_NO_BNB_Y");
     if (no_y || conv_up2_applicable(a) || conv_head_applicable(a) || conv_head_dgrad_applicable(a) || conv_patch16_applicable(a)) return false;
     if (wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)) return true;      // (launch_conv_wino skips the 8-wave variant when bnb_mean is set)
     return !conv_patch_applicable(a);
   }
-  static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr;
+  static const bool no_up2 = dbg_flag("UWM_NO_UP2");
   if (a.out_up) return (!no_up2 && conv_up2_dgrad_applicable(a)) || (a.prec == 1 ? conv_wino_x3_applicable(a) : conv_wino_applicable(a));
-  static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
+  static const bool no_head = dbg_flag("UWM_NO_CONV_HEAD");
   if (!no_up2 && conv_up2_applicable(a)) return false;
   if (!no_head && conv_head_applicable(a)) return false;
   if (!no_head && conv_head_dgrad_applicable(a)) return true;
@@ -340,7 +340,7 @@ bool conv_routes_to_wino(const ConvArgs& a) {
     return a.prec == 1 || !conv_wino8_applicable(a);      // (the 8-wave variant has no fused BatchNorm-backward sums)
   if (conv_patch16_applicable(a)) return true;
   if (conv_patch_applicable(a)) return false;             // (direct 3x3 kernels of Winograd mode 0: no bnb epilogue)
-  static const bool no_igemm_bnb = getenv("UWM_NO_IGEMM_BNB") != nullptr;
+  static const bool no_igemm_bnb = dbg_flag("UWM_NO_IGEMM_BNB");
   return !no_igemm_bnb;                                   // flattened implicit GEMM / stride-2 parity classes (conv_igemm.hip)
 }
 
@@ -348,7 +348,7 @@ bool conv_routes_to_wino(const ConvArgs& a) {
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (a.M <= 0 || a.Cout <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int cfg = force_cfg;
-  static const bool trace = getenv("UWM_TRACE_CONV") != nullptr;
+  static const bool trace = dbg_flag("UWM_TRACE_CONV");
   if (trace)
     fprintf(stderr, "conv %s N=%d Ctot=%d(C0=%d up=%d) Cout=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d smul=%d sdiv=%d wino=%d gflop=%.2f\n",
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
@@ -359,15 +359,15 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (cfg == 400) return launch_conv_wino_x3(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
   if (a.out_up) {                                                  // fused concat split: Winograd epilogues (and the sub-pixel dgrad of conv_up2.hip)
-    static const bool no_up2d = getenv("UWM_NO_UP2") != nullptr;
+    static const bool no_up2d = dbg_flag("UWM_NO_UP2");
     if (cfg < 0 && !no_up2d && conv_up2_dgrad_applicable(a)) return launch_conv_up2_dgrad(a, st);
     if (a.prec == 1) return launch_conv_wino_x3(a, st);
     return conv_wino_applicable(a) ? launch_conv_wino(a, st) : hipErrorInvalidValue;
   }
   if (cfg == 200) return launch_conv_patch16(a, st);
-  static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr;
+  static const bool no_up2 = dbg_flag("UWM_NO_UP2");
   if (cfg < 0 && !no_up2 && conv_up2_applicable(a)) return launch_conv_up2(a, st);      // sub-pixel decomposition: Winograd's 2.25x without transforms
-  static const bool no_head = getenv("UWM_NO_CONV_HEAD") != nullptr;
+  static const bool no_head = dbg_flag("UWM_NO_CONV_HEAD");
   if (cfg < 0 && !no_head && conv_head_applicable(a)) return launch_conv_head(a, st);
   if (cfg < 0 && !no_head && conv_head_dgrad_applicable(a)) return launch_conv_head_dgrad(a, st);      // few channels -> <= 4 classes: HBM streaming kernel
   // 16-channel inputs at full resolution are HBM-bound: the one-barrier direct kernel beats the Winograd pipeline there
@@ -394,7 +394,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
       const long b0 = tiles128 * ((a.Cout + 127) / 128);
       // 1x1 layers with channel counts like 144 or 192 (MBConv expand / project dgrad): the 128-wide tile pads them to 256;
       // the 64-wide tile wastes far fewer MFMAs and LDS reads
-      static const bool narrow = getenv("UWM_NO_NARROW_1X1") == nullptr;
+      static const bool narrow = !dbg_flag("UWM_NO_NARROW_1X1");
       const int pad128 = ((a.Cout + 127) / 128) * 128, pad64 = ((a.Cout + 63) / 64) * 64;
       if (narrow && a.ntaps == 1 && pad128 * 100 > pad64 * 115 && tiles128 * (pad64 / 64) >= 512) cfg = 1;
       else if (b0 >= 512) cfg = 0;

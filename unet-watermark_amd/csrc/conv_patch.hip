@@ -284,6 +284,7 @@ bool conv_patch_applicable(const ConvArgs& a) {
 // bn: 128 | 64 | 32 | 16 output channels per workgroup
 hipError_t launch_conv_patch(const ConvArgs& a, hipStream_t st, int bn) {
   if (!conv_patch_applicable(a) || (a.Cout & 3)) return hipErrorInvalidValue;
+  if (a.bnb_mean) return hipErrorInvalidValue;      // no fused BatchNorm-backward sums in this epilogue: it would write (v, v^2) into the replicas
   if (bn <= 0) bn = a.Cout >= 128 ? 128 : (a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16));
   switch (bn) {
     case 128: return launch_p<128, 2, 2>(a, st, 10);

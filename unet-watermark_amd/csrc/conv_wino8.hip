@@ -286,6 +286,7 @@ bool conv_wino8_applicable(const ConvArgs& a) {
 
 hipError_t launch_conv_wino8(const ConvArgs& a, hipStream_t st) {
   if (!conv_wino_applicable(a) || a.Cout < 64 || a.Ho < kT8 || a.Wo < kT8) return hipErrorInvalidValue;
+  if (a.bnb_mean) return hipErrorInvalidValue;      // no fused BatchNorm-backward sums in this epilogue (conv_wino_kernel<NI> carries them)
   const int tilesN = (a.Cout + 63) / 64;
   const int tilesW = (a.Wo + kT8 - 1) / kT8, tilesH = (a.Ho + kT8 - 1) / kT8;
   const size_t main_lds = (size_t)(2 * kUs8 + 2 * kPb8) * sizeof(float);

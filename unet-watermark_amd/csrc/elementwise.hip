@@ -5,6 +5,8 @@
 // and optim.Adam as driven by /root/reference/src/train.py:96-105 (SURVEY.md §8 a4,a9,a10,a14,a15).
 #include "uwm_kernels.h"
 #include <vector>
+#include <mutex>
+#include <cstdlib>
 
 namespace uwm {
 
@@ -651,22 +653,34 @@ hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ HIP-event profiler (host side)
+bool dbg_flag(const char* name) {
+  static const bool on = [] { const char* e = getenv("UWM_DEBUG"); return e && e[0] == '1'; }();
+  return on && getenv(name) != nullptr;
+}
+int dbg_int(const char* name, int dflt) {
+  if (!dbg_flag(name)) return dflt;
+  return atoi(getenv(name));
+}
+
 struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
-static bool g_prof = false;
+static std::atomic<bool> g_prof{false};
+static std::mutex g_prof_mu;                      // records / event pool: launches may come from one host thread per GPU
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
-static hipEvent_t prof_event() {
+static hipEvent_t prof_event() {                  // g_prof_mu held
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 void prof_enable(bool on) { g_prof = on; }
 bool prof_on() { return g_prof; }
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r; r.cls = cls; r.flops = flops; r.bytes = bytes; r.e0 = prof_event(); r.e1 = prof_event();
   *e0 = r.e0; *e1 = r.e1;
   g_recs.push_back(r);
 }
 int prof_collect(double* out) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < kProfClasses * 4; ++i) out[i] = 0.0;
   for (auto& r : g_recs) {
     (void)hipEventSynchronize(r.e1);

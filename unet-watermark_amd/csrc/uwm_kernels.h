@@ -9,6 +9,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 
 namespace uwm {
 
@@ -31,16 +32,22 @@ static inline FastDiv make_fastdiv(unsigned d) {
 // ---- per-device launch state.  hipFuncSetAttribute and the CU count belong to a DEVICE, not to the process: one flag
 // per (kernel instantiation, device), so a process that drives several GPUs sets the attribute on each of them.
 struct DevOnce {
-  unsigned long long mask = 0;
+  std::atomic<unsigned long long> mask{0};          // one host thread per GPU may race here: the attribute call is idempotent, the bit set is atomic
   hipError_t set_max_lds(const void* fn, size_t bytes) {
     int dev = 0; hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 64 && ((mask >> dev) & 1ull)) return hipSuccess;
+    if (dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess && dev < 64) mask |= 1ull << dev;
+    if (e == hipSuccess && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release);
     return e;
   }
 };
+// ---- debug switches: ONE gate.  Every routing / ablation switch of the library (UWM_NO_*, UWM_TRACE_CONV, UWM_WGRAD_V1, UWM_WW_TA:
+// INTEGRATION.md 2b) is read through dbg_flag() / dbg_int(), which answer "unset" unless UWM_DEBUG=1 is in the environment — a
+// production process cannot be re-routed by a stray variable.  (UWM_WINOGRAD and UWM_SIDE_STREAM are documented process
+// defaults of public setters, not debug switches.)
+bool dbg_flag(const char* name);                // UWM_DEBUG=1 and `name` set
+int dbg_int(const char* name, int dflt);        // UWM_DEBUG=1 and `name` set ? atoi : dflt
 int device_cu_count();       // compute units of the CURRENT device (cached per device)
 
 struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (transposed gather)
@@ -125,7 +132,7 @@ const char* prof_class_name(int cls);
 
 // ---- launchers (all asynchronous on `st`, no host sync, no allocation) ----
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg = -1);
-bool conv_routes_to_wino(const ConvArgs& a);      // launch_conv (auto routing) will run this launch on conv_wino / conv_wino_x3 (the epilogues that can carry bnb_*)
+bool conv_epilogue_carries_bnb(const ConvArgs& a);      // launch_conv (auto routing) ends on a kernel whose epilogue carries the fused BatchNorm-backward sums (bnb_*); every launcher that cannot REJECTS a.bnb_mean, so a disagreement with the router is an error, not a wrong dgamma
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t st);
 // 3x3 s1 p1 patch-tiled conv (conv_patch.hip); launch_conv routes to it when applicable.
 // force_cfg for launch_conv: -1 auto, 0..5 conv_igemm tile config, 100+BN (116,132,164,228) conv_patch, 200 conv_patch16

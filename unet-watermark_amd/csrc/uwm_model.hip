@@ -547,9 +547,9 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.wino = c.m->plan.wino_mode + 1;
   if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
   if (fused) *fused = false;
-  static const bool no_fuse = getenv("UWM_NO_BN_FUSE") != nullptr;
-  a.bnb_y = bn_y;                                  // (consulted by conv_routes_to_wino; cleared again when the sums are not fused)
-  if (bn_fuse >= 0 && fused && !no_fuse && (us ? (us->pmask != nullptr && !us->accumulate) : (mask != nullptr || bn_y != nullptr)) && conv_routes_to_wino(a)) {
+  static const bool no_fuse = dbg_flag("UWM_NO_BN_FUSE");
+  a.bnb_y = bn_y;                                  // (consulted by conv_epilogue_carries_bnb; cleared again when the sums are not fused)
+  if (bn_fuse >= 0 && fused && !no_fuse && (us ? (us->pmask != nullptr && !us->accumulate) : (mask != nullptr || bn_y != nullptr)) && conv_epilogue_carries_bnb(a)) {
     const BNL& b = c.m->bns[bn_fuse];
     if (b.C == (us ? us->C0 : cv.CinP)) {
       const float* f = c.F(b.f_off);
@@ -1085,7 +1085,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       // the masked gradient it writes is the gradient wrt the stem BatchNorm's output and it reads that BatchNorm's raw input
       // for the mask anyway: the BatchNorm-backward sums ride along (replicas of the forward statistics, re-zeroed above)
       const BNL& sb = m->bns[m->convs[m->stem].bn];
-      static const bool no_fuse = getenv("UWM_NO_BN_FUSE") != nullptr;
+      static const bool no_fuse = dbg_flag("UWM_NO_BN_FUSE");
       const bool pool_sums = !no_fuse && f1.scale && f1.relu && sb.C == f1.C && (256 % (f1.C / 4)) == 0;
       LCHK(launch_maxpool_bwd(c.F(p.g_pool), (const uint8_t*)c.F(p.pool_idx), c.F(p.gskip[3]), f1, c.F(p.g[m->stem]), N,
                               sh[0], sw[0], st, pool_sums ? c.F(sb.f_off) : nullptr, pool_sums ? c.F(sb.f_off) + sb.C : nullptr,

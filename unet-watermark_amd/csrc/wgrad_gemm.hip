@@ -144,7 +144,7 @@ bool wgrad_gemm_preferred(const WgradArgs& a) {
 }
 
 bool wgrad_gemm_applicable(const WgradArgs& a) {
-  static const bool off = getenv("UWM_NO_WGRAD_GEMM") != nullptr;
+  static const bool off = dbg_flag("UWM_NO_WGRAD_GEMM");
   return !off && a.ntaps == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.s0.up == 0 && a.C0 == a.Ctot && a.s0.C == a.Ctot &&
          (a.Ctot & 3) == 0 && a.Kpad == ((a.Ctot + 31) & ~31) && (a.Cout & 3) == 0 && a.Cout >= 32 && a.Ctot >= 16 && (a.M & 31) == 0 && a.M >= 256 &&
          a.Hl == a.Ho && a.Wl == a.Wo && a.s0.H == a.Ho && a.s0.W == a.Wo;

@@ -207,14 +207,14 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
 
 // tile (output channels x k-columns) chosen from the layer's Cout: 16x256, 32x256, 64x128, 128x128
 hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
-  static const bool trace = getenv("UWM_TRACE_CONV") != nullptr;
+  static const bool trace = dbg_flag("UWM_TRACE_CONV");
   if (trace)
     fprintf(stderr, "wgrad N=%d Ctot=%d(C0=%d) Cout=%d wrows=%d Ho=%d Wo=%d Hl=%d Wl=%d taps=%d stride=%d wino=%d patch=%d gflop=%.2f\n", a0.N, a0.Ctot,
             a0.C0, a0.Cout, a0.wrows, a0.Ho, a0.Wo, a0.Hl, a0.Wl, a0.ntaps, a0.stride, (int)(wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)),
             (int)wgrad_patch_applicable(a0), a0.flops * 1e-9);
   // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd, 4 = wgrad_gemm.hip wherever applicable
   if ((a0.force_igemm & 0xff) == 4) return launch_wgrad_gemm(a0, st);
-  static const bool no_up2 = getenv("UWM_NO_UP2") != nullptr || getenv("UWM_NO_UP2_WGRAD") != nullptr;
+  static const bool no_up2 = dbg_flag("UWM_NO_UP2") || dbg_flag("UWM_NO_UP2_WGRAD");
   if ((a0.force_igemm & 0xff) == 0 && !no_up2 && wgrad_up2_applicable(a0)) return launch_wgrad_up2(a0, st);      // sub-pixel form of conv-after-upsample
   if ((a0.force_igemm & 0xff) == 0 && wgrad_stem_applicable(a0)) return launch_wgrad_stem(a0, st);         // the ResNet stem: compact K = 147
   if ((a0.force_igemm & 0xff) == 0 && wgrad_gemm_preferred(a0)) return launch_wgrad_gemm(a0, st);        // 1x1 / stride 1: persistent LDS-DMA GEMM, deterministic
@@ -227,7 +227,7 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   // 1x1 layers (MBConv expand / project, Bottleneck): the k extent is just the input channel count (Kpad 32..2688), so a
   // narrower k tile is taken when it cuts the padded columns by >= 15 % (a 128-column tile on Kpad = 32 spends 3/4 of its
   // MFMAs and LDS traffic on zeros)
-  static const bool narrow = getenv("UWM_NO_NARROW_WGRAD") == nullptr;
+  static const bool narrow = !dbg_flag("UWM_NO_NARROW_WGRAD");
   auto padded = [&](int tb) { return (a.Kpad + tb - 1) / tb * tb; };
   if (a.wrows <= 16) { TA = 16; TB = 256; }
   else if (a.wrows <= 32) {

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_reduce_kernel(const float* __r
 }
 
 bool wgrad_stem_applicable(const WgradArgs& a) {
-  static const bool off = getenv("UWM_NO_WGRAD_STEM") != nullptr;
+  static const bool off = dbg_flag("UWM_NO_WGRAD_STEM");
   return !off && a.ntaps == 49 && a.kw == 7 && a.stride == 2 && a.pad == 3 && a.s0.up == 0 && a.C0 == a.Ctot && a.Ctot == 4 && a.s0.C == 4 &&
          a.Cout == 64 && a.wrows <= 64 && a.Kpad >= 196 && a.s0.scale == nullptr && 2 * a.Ho == a.s0.H && 2 * a.Wo == a.s0.W &&
          (a.Ho % kSR) == 0 && (a.Wo % kSC) == 0;

@@ -576,7 +576,7 @@ float* wgrad_op_scratch() {                   // single-operator entry points (n
 template <int TA>
 static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nblocks) {
   size_t lds = (size_t)(2 * 64 * TA + 2 * kPP * kCW) * sizeof(float);
-  static const bool v1 = getenv("UWM_WGRAD_V1") != nullptr;        // experiments: the round-1 row-per-wave kernel for every TA
+  static const bool v1 = dbg_flag("UWM_WGRAD_V1");        // experiments: the round-1 row-per-wave kernel for every TA
   if (TA == 16 || v1) {
     const size_t rl = (size_t)9 * TA * kCW * sizeof(float);
     if (lds < rl) lds = rl;
@@ -598,7 +598,7 @@ static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nbl
 bool wgrad_wino_applicable(const WgradArgs& a) {
   const int TA = a.Cout >= 64 ? 64 : a.Cout;
   // channel tail (wgrad_wino2 only, TA >= 32): Ctot % 8 == 0 with the concat boundary on a 32-channel chunk
-  static const bool v1 = getenv("UWM_WGRAD_V1") != nullptr;
+  static const bool v1 = dbg_flag("UWM_WGRAD_V1");
   const bool tail_ok = TA >= 32 && !v1 && (a.Ctot & 7) == 0 && (a.Ctot - a.C0 == 0 || (a.Ctot - a.C0) >= 4);
   return a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && ((a.Ctot & 31) == 0 || tail_ok) && ((a.C0 & 31) == 0 || (tail_ok && a.C0 == a.Ctot)) &&
          (TA == 64 || TA == 32 || TA == 16) && a.Cout % TA == 0 && a.wrows <= a.Cout && a.Kpad >= 9 * a.Ctot && a.Kpad < 9 * a.Ctot + 32 &&
@@ -609,7 +609,7 @@ hipError_t launch_wgrad_wino(const WgradArgs& a0, hipStream_t st) {
   WgradArgs a = a0;
   if (!wgrad_wino_applicable(a)) return hipErrorInvalidValue;
   int TA = a.Cout >= 64 ? 64 : a.Cout;
-  static const int force_ta = getenv("UWM_WW_TA") ? atoi(getenv("UWM_WW_TA")) : 0;      // experiments
+  static const int force_ta = dbg_int("UWM_WW_TA", 0);      // experiments
   if (force_ta && TA > force_ta && a.Cout % force_ta == 0) TA = force_ta;
   const int nchunk = (a.Ctot + kCW - 1) / kCW, tilesA = a.Cout / TA;
   const int nstages = a.N * (a.Ho / kSH) * (a.Wo / kSW);

@@ -148,7 +148,7 @@ class Unet(nn.Module):
         self._mb_drop = [float(lib.uwm_mbconv_drop_rate(h, i)) for i in range(self._n_mb)]
         self.drop_connect = self._n_mb > 0
         self.precision = "f32"
-        self._arena_grads_only = False    # set by the fused flat optimizers: backward() leaves p.grad unset, gradients stay in the arena
+        self._fused_opt_ref = None        # weakref to the fused flat optimizer that consumes the gradient arena itself (train.py)
         self._keep_override = None        # tests: {0,1} keep masks [n_blocks, N] instead of a random draw
         self._rowscale = None
         self.reset_parameters()
@@ -208,6 +208,14 @@ class Unet(nn.Module):
     @property
     def device(self):
         return self._param_arena.device
+
+    @property
+    def _arena_grads_only(self) -> bool:
+        """True while a LIVE fused flat optimizer (train.py) owns the gradient arena: backward() then leaves `p.grad` unset.
+        The flag dies with that optimizer (or its close()), so a torch.optim optimizer, clip_grad_norm_ or a gradient
+        check used on the same model afterwards sees populated `p.grad` again."""
+        ref = self._fused_opt_ref
+        return ref is not None and ref() is not None
 
     def flat_parameters(self) -> torch.Tensor:
         """The flat fp32 parameter arena (padding included; padding is always zero)."""

@@ -10,16 +10,13 @@ RCCL over xGMI) carrying one all-reduce per backward stage on a side HIP stream.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 from . import _lib as L
-
-
-import os as _os
-_NOOP_COLLECTIVES = bool(_os.environ.get("UWM_DDP_NOOP"))
 
 
 class GradReducer:
@@ -48,8 +45,6 @@ class GradReducer:
             return
         b, e = self.buckets[k]
         view = self.flat[b:e]
-        if _NOOP_COLLECTIVES:          # experiments only: keep the stream/event structure, skip the collective
-            return
         if self.on_gpu:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
@@ -100,7 +95,15 @@ class _FusedFlatOptimizer(torch.optim.Optimizer):
         self._bufs = None
         self._step = 0
         self._checked_flags = None
-        model._arena_grads_only = not materialize_grads
+        # the autograd path skips the per-parameter gradient copies only while THIS optimizer is alive (weak reference):
+        # dropping it, or close(), gives `p.grad` back to torch.optim / clip_grad_norm_ / gradient checks on the same model
+        model._fused_opt_ref = None if materialize_grads else weakref.ref(self)
+
+    def close(self):
+        """Give the model's autograd path its per-parameter `p.grad` back (undo of materialize_grads=False)."""
+        ref = getattr(self.model, "_fused_opt_ref", None)
+        if ref is not None and ref() is self:
+            self.model._fused_opt_ref = None
 
     def _state_init(self):
         p = self.model.flat_parameters()
@@ -178,7 +181,9 @@ class _FusedFlatOptimizer(torch.optim.Optimizer):
                         return
                     views[i].copy_(t.to(views[i].device))
                 step = max(step, int(float(ent.get("step", 0))))
-            self._step = step
+            # torch.optim.SGD keeps no 'step': a loaded momentum buffer must not be taken for an uninitialised one (the
+            # kernel's first step overwrites the buffer with the raw gradient), so restored state counts as >= 1 step
+            self._step = max(step, 1) if len(st) else step
         elif "step" in sd and all(nm in sd for nm in self._SLOTS):      # round-1 flat-arena layout
             self._step = int(sd["step"])
             for b, nm in zip(self._bufs, self._SLOTS):
