@@ -185,6 +185,8 @@ def validate_ddp(trainer, model, x, t, world, rank, dev):
     m = model
     n, _, h, w = x.shape
     nst = len(m.stages)
+    # the check leaves no trace: parameters, BatchNorm buffers and counters are put back afterwards, the optimizer restarts
+    snap = (m.flat_parameters().clone(), m._buffer_arena.clone(), m._nbt_arena.clone())
     # (1) local backward of the same batch, no exchange, no optimizer step
     logits = m._forward_raw(x, training=True)
     trainer._buffers(n, h, w, dev)
@@ -245,6 +247,11 @@ def validate_ddp(trainer, model, x, t, world, rank, dev):
             print(json.dumps({"ddp_check": "FAILED", "rank": rank, "problems": problems, "buckets": rows}), file=sys.stderr, flush=True)
         dist.barrier(device_ids=[dev.index])
         sys.exit(3)
+    m.flat_parameters().copy_(snap[0]); m._buffer_arena.copy_(snap[1]); m._nbt_arena.copy_(snap[2])
+    for b_ in (trainer.opt._bufs or []):
+        b_.zero_()
+    trainer.opt._step = 0
+    torch.cuda.synchronize(dev)
     return {"ranks": world, "buckets": rows, "params_bit_identical_after_step1": bool(psame),
             "local_grad_l1_per_rank": [float(f"{v:.6e}") for v in lvals]}
 
