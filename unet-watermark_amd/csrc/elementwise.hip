@@ -175,7 +175,7 @@ hipError_t launch_maxpool_fwd(const Src& in, float* out, uint8_t* idx, int N, in
 
 // bn_mean != nullptr: the masked gradient this kernel writes is the gradient wrt the output of the BatchNorm whose raw input
 // it has just read for the ReLU mask (the stem: conv -> bn -> relu -> maxpool), so the BatchNorm-backward sums (dbeta = sum g,
-// dgamma = sum g * yhat) are accumulated here, one of `srep` fp64 replicas per workgroup (folded by bn_bwd_fold_kernel):
+// dgamma = sum g * yhat) are accumulated here, one of `srep` fp64 replicas per workgroup (added up in bn_bwd_apply_kernel's prologue):
 // bn_bwd_reduce's pass over both tensors disappears.  Needs gridDim.x * 256 to be a multiple of C/4 (a thread keeps its channels).
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ idx,
                                    const float* __restrict__ addend, const Src in, float* __restrict__ gin, int Ho,
@@ -296,55 +296,87 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const double* __restrict__ rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta) {
-  // same shape as bn_finalize_kernel: 16 channels x 16 replica lanes, fixed xor tree
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), r0 = threadIdx.x & 15;
-  const bool live = c < C;
-  double sb = 0.0, sg = 0.0;
-  if (live)
-    for (int r = r0; r < nrep; r += 16) { sb += rep[(size_t)r * rep_stride + c]; sg += rep[(size_t)r * rep_stride + C + c]; }
-#pragma unroll
-  for (int d = 1; d < 16; d <<= 1) { sb += shfl_xor_f64(sb, d); sg += shfl_xor_f64(sg, d); }
-  if (live && r0 == 0) { dbeta[c] = sb; dgamma[c] = sg; }
-}
-hipError_t launch_bn_bwd_fold(const double* rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, rep, nrep, rep_stride, C, dgamma, dbeta);
-  return hipGetLastError();
-}
-
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
+// rep != nullptr: the sums arrive as `nrep` per-workgroup replicas {dbeta part[C], dgamma part[C]} a fused dgrad epilogue filled
+// (run_dgrad bn_fuse); the workgroup adds them up itself for the channels it touches, in a fixed order (bit-reproducible, the
+// same value in every workgroup) — the separate bn_bwd_fold launch between every dgrad and its apply pass (42 per resnet34
+// step, each queued behind the other stream's workgroups: 1.2 ms of critical-path latency) is gone.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const double* __restrict__ dgamma, const double* __restrict__ dbeta, float* __restrict__ dy,
-                                    float* gamma_grad, float* beta_grad, size_t n4, int C, float invM) {
-  if (blockIdx.x == 0 && gamma_grad) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) { gamma_grad[c] = (float)dgamma[c]; beta_grad[c] = (float)dbeta[c]; }
-  }
+                                    float* gamma_grad, float* beta_grad, size_t n4, int C, float invM,
+                                    const double* __restrict__ rep, int nrep, int rep_stride) {
+  __shared__ double part[256 * 8];
   // dy = gm*rs*(g - db - (y-mu)*rs*dg) = A*g + B*y + K per channel; the grid stride is a multiple of C/4, so a thread
   // keeps ONE channel quad: coefficients computed once, four 16-byte loads of each tensor in flight per iteration
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n4) return;
+  const int Q = C >> 2;
   const int c = (int)((i * 4) % (size_t)C);
+  // the first iteration's eight 16-byte loads do not depend on the sums: they are in flight while the prologue runs
+  f4 g0, g1, g2, g3, y0, y1, y2, y3;
+  bool full = i + 3 * stride < n4;
+  if (full) {
+    g0 = *(const f4*)(g + i * 4); g1 = *(const f4*)(g + (i + stride) * 4); g2 = *(const f4*)(g + (i + 2 * stride) * 4); g3 = *(const f4*)(g + (i + 3 * stride) * 4);
+    y0 = *(const f4*)(y + i * 4); y1 = *(const f4*)(y + (i + stride) * 4); y2 = *(const f4*)(y + (i + 2 * stride) * 4); y3 = *(const f4*)(y + (i + 3 * stride) * 4);
+  }
   const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), gm = *(const f4*)(gamma + c);
+  double sdb[4], sdg[4];
+  if (rep) {
+    // the workgroup touches quads (q0 + t) % Q, t < 256: nq distinct ones; L replica lanes per quad share the nrep copies
+    const int nq = Q < 256 ? Q : 256, L = 256 / nq;
+    const int q0 = (int)(((size_t)blockIdx.x * 256) % (size_t)Q);
+    const int j = threadIdx.x % nq, l = threadIdx.x / nq;
+    if (l < L) {
+      const int cj = ((q0 + j) % Q) * 4;
+      double b0 = 0, b1 = 0, b2 = 0, b3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+      for (int r = l; r < nrep; r += L) {
+        const double* pr = rep + (size_t)r * rep_stride + cj;
+        b0 += pr[0]; b1 += pr[1]; b2 += pr[2]; b3 += pr[3];
+        d0 += pr[C]; d1 += pr[C + 1]; d2 += pr[C + 2]; d3 += pr[C + 3];
+      }
+      double* o = part + (l * nq + j) * 8;
+      o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = d0; o[5] = d1; o[6] = d2; o[7] = d3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sdb[e] = 0.0; sdg[e] = 0.0; }
+    for (int k = 0; k < L; ++k) {                    // fixed order over the replica lanes
+      const double* o = part + (k * nq + j) * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sdb[e] += o[e]; sdg[e] += o[4 + e]; }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sdb[e] = dbeta[c + e]; sdg[e] = dgamma[c + e]; }
+  }
+  if (gamma_grad && i < (size_t)Q) {                   // the first Q threads of the grid hold every channel quad once
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gamma_grad[c + e] = (float)sdg[e]; beta_grad[c + e] = (float)sdb[e]; }
+  }
+  if (i >= n4) return;
   f4 dg, db;
-  dg.x = (float)dgamma[c] * invM; dg.y = (float)dgamma[c + 1] * invM; dg.z = (float)dgamma[c + 2] * invM; dg.w = (float)dgamma[c + 3] * invM;
-  db.x = (float)dbeta[c] * invM; db.y = (float)dbeta[c + 1] * invM; db.z = (float)dbeta[c + 2] * invM; db.w = (float)dbeta[c + 3] * invM;
+  dg.x = (float)sdg[0] * invM; dg.y = (float)sdg[1] * invM; dg.z = (float)sdg[2] * invM; dg.w = (float)sdg[3] * invM;
+  db.x = (float)sdb[0] * invM; db.y = (float)sdb[1] * invM; db.z = (float)sdb[2] * invM; db.w = (float)sdb[3] * invM;
   const f4 A = gm * rs, B = -(gm * rs * rs * dg), K = -(A * db) - B * mu;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const f4 g0 = *(const f4*)(g + i * 4), g1 = *(const f4*)(g + (i + stride) * 4), g2 = *(const f4*)(g + (i + 2 * stride) * 4),
-             g3 = *(const f4*)(g + (i + 3 * stride) * 4);
-    const f4 y0 = *(const f4*)(y + i * 4), y1 = *(const f4*)(y + (i + stride) * 4), y2 = *(const f4*)(y + (i + 2 * stride) * 4),
-             y3 = *(const f4*)(y + (i + 3 * stride) * 4);
-    *(f4*)(dy + i * 4) = A * g0 + B * y0 + K;
-    *(f4*)(dy + (i + stride) * 4) = A * g1 + B * y1 + K;
-    *(f4*)(dy + (i + 2 * stride) * 4) = A * g2 + B * y2 + K;
-    *(f4*)(dy + (i + 3 * stride) * 4) = A * g3 + B * y3 + K;
+  while (full) {
+    const f4 o0 = A * g0 + B * y0 + K, o1 = A * g1 + B * y1 + K, o2 = A * g2 + B * y2 + K, o3 = A * g3 + B * y3 + K;
+    const size_t io = i;
+    i += 4 * stride;
+    full = i + 3 * stride < n4;
+    if (full) {                                        // next iteration's loads before this one's stores
+      g0 = *(const f4*)(g + i * 4); g1 = *(const f4*)(g + (i + stride) * 4); g2 = *(const f4*)(g + (i + 2 * stride) * 4); g3 = *(const f4*)(g + (i + 3 * stride) * 4);
+      y0 = *(const f4*)(y + i * 4); y1 = *(const f4*)(y + (i + stride) * 4); y2 = *(const f4*)(y + (i + 2 * stride) * 4); y3 = *(const f4*)(y + (i + 3 * stride) * 4);
+    }
+    *(f4*)(dy + io * 4) = o0;
+    *(f4*)(dy + (io + stride) * 4) = o1;
+    *(f4*)(dy + (io + 2 * stride) * 4) = o2;
+    *(f4*)(dy + (io + 3 * stride) * 4) = o3;
   }
   for (; i < n4; i += stride) *(f4*)(dy + i * 4) = A * *(const f4*)(g + i * 4) + B * *(const f4*)(y + i * 4) + K;
 }
 hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                                const double* dgamma, const double* dbeta, float* dy, float* gamma_grad, float* beta_grad,
-                               size_t npix, int C, hipStream_t st) {
+                               size_t npix, int C, hipStream_t st, const double* rep, int nrep, int rep_stride, hipEvent_t done) {
   const size_t n4 = npix * C / 4;
   // grid stride (blocks x 256) must be a multiple of C/4 so that every thread stays on one channel quad
   unsigned nb = nblocks(n4, 256 * 4);
@@ -352,8 +384,16 @@ hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean
   unsigned unit = q;                               // smallest block count with (nb*256) % q == 0: q / gcd(q, 256)
   { unsigned a = q, b = 256; while (b) { unsigned t = a % b; a = b; b = t; } unit = q / a; }
   nb = ((nb + unit - 1) / unit) * unit;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, st, g, y, mean, rstd, gamma, dgamma,
-                     dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix));
+  if ((size_t)nb * 256 < q) nb = ((q + 255) / 256 + unit - 1) / unit * unit;      // (tiny tensors: the grid must still hold every channel quad for the gamma / beta gradients)
+  // done: an event attached to THIS dispatch's completion signal (hipExtLaunchKernelGGL) — the weight-gradient stream forks
+  // from it without a barrier packet of its own on this stream (a hipEventRecord between this kernel and the next dgrad cost
+  // ~8 us of queue-processing latency on the dependent chain, 40 times per step)
+  if (done)
+    hipExtLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, st, nullptr, done, 0, g, y, mean, rstd, gamma, dgamma,
+                          dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix), rep, rep ? (nrep < 1 ? 1 : nrep) : 0, rep_stride);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, st, g, y, mean, rstd, gamma, dgamma,
+                       dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix), rep, rep ? (nrep < 1 ? 1 : nrep) : 0, rep_stride);
   return hipGetLastError();
 }
 

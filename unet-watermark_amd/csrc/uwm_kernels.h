@@ -91,6 +91,18 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int prec;                  // 1: wu is a bf16x3 bank (conv_wino_x3.hip layout) and the launch goes to the split-bf16 kernel; 0: fp32
 };
 
+// Deferred partial-sum reduces.  A split weight-gradient launch leaves `nsplit` dW-shaped partial images in scratch; adding them
+// up (fixed order) used to be one small launch behind every wgrad (37 per resnet34 step, each 3x slower beside the other
+// stream's kernels than alone).  With a queue attached (WgradArgs::rq) the launcher only records the job; the owner flushes the
+// queue with ONE multi-job launch per backward stage (launch_wgrad_reduce_multi) — same arithmetic per job, so the result is
+// bit-identical to the immediate form.  The owner hands every queued job its own scratch region (rq->used_floats).
+struct ReduceJob { const float* part; float* dw; unsigned long long n4; int nsplit; unsigned block0; };
+struct ReduceQueue {
+  enum { kMax = 48 };
+  ReduceJob j[kMax]; int n = 0; unsigned blocks = 0; size_t used_floats = 0;
+};
+struct ReduceJobs { ReduceJob j[ReduceQueue::kMax]; int n; };
+
 struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = tap*Ctot + c)
   Src s0, s1; int C0, Ctot;
   const float* dy;           // [M][Cout]
@@ -106,6 +118,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
   double bytes;              // algorithmic HBM bytes of this launch: every operand read once + the output written once (profiling only)
   int wino;                  // as ConvArgs::wino
+  ReduceQueue* rq;           // HOST pointer (never read on the device) or nullptr: queue the partial-sum reduce instead of launching it
 };
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
@@ -144,7 +157,8 @@ size_t wgrad_wino_scratch_floats();                         // workspace the mod
 float* wgrad_op_scratch();                                  // the same, for the single-operator entry points (cached per device)
 bool wgrad_c16_applicable(const WgradArgs& a);              // 16-channel full-resolution layers and the head (wgrad_c16.hip)
 hipError_t launch_wgrad_c16(const WgradArgs& a, hipStream_t st);
-hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st);      // dw += sum of nsplit full-size partial images, fixed order
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st, ReduceQueue* rq = nullptr);      // dw += sum of nsplit full-size partial images, fixed order; rq: queued, not launched
+hipError_t launch_wgrad_reduce_multi(ReduceQueue& q, hipStream_t st);        // every queued job in one launch; empties the queue
 bool wgrad_stem_applicable(const WgradArgs& a);             // 7x7 / stride-2 / 3(4)-channel stem: compact-column wgrad (wgrad_stem.hip)
 hipError_t launch_wgrad_stem(const WgradArgs& a, hipStream_t st);
 bool wgrad_gemm_applicable(const WgradArgs& a);             // 1x1 / stride-1 weight gradient as a persistent LDS-DMA GEMM (wgrad_gemm.hip)
@@ -210,9 +224,8 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
                                 double* dgamma, double* dbeta, size_t npix, int C, hipStream_t st);
 hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd,
                                const float* gamma, const double* dgamma, const double* dbeta, float* dy,
-                               float* gamma_grad, float* beta_grad, size_t npix, int C, hipStream_t st);
-// dgamma[c] / dbeta[c] = sum over the nrep replicas {dbeta part[C], dgamma part[C]} a fused dgrad epilogue filled
-hipError_t launch_bn_bwd_fold(const double* rep, int nrep, int rep_stride, int C, double* dgamma, double* dbeta, hipStream_t st);
+                               float* gamma_grad, float* beta_grad, size_t npix, int C, hipStream_t st,
+                               const double* rep = nullptr, int nrep = 0, int rep_stride = 0, hipEvent_t done = nullptr);   // rep: fold the nrep replicas {dbeta part[C], dgamma part[C]} of a fused dgrad epilogue in the prologue (dgamma / dbeta unused)
 // dcat [N][H][W][C0+C1] -> gprev [N][H/2][W/2][C0] = mask(sum 2x2), gskip [N][H][W][C1] (copy)
 hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev,
                           const float* pmask, const float* pscale, const float* pshift, float* gskip,

@@ -65,6 +65,7 @@ struct NodeL { int c1, c2, prev; std::vector<int> skips; int C0, C1, lvl; };
 // project 1x1 -> BN [-> drop-connect + identity].  ce = -1 when expand_ratio == 1.
 struct MBL { int ce = -1, cdw = -1, cr = -1, cx = -1, cp = -1, Cin = 0, Cout = 0, mid = 0, nsq = 0, k = 3, stride = 1, pb = 0; bool skip = false; float drop = 0.f; };
 
+constexpr size_t kWgParts = 8;      // partial-sum scratch: room for this many worst-case split launches between two flushes of the reduce queue
 struct Plan {                       // workspace layout for one (N,H,W,training)
   int N = 0, H = 0, W = 0, training = -1;
   size_t bytes = 0;
@@ -115,6 +116,9 @@ struct uwm_model {
   // with events (capturable fork-join; no host synchronisation)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+  hipEvent_t ev_disp = nullptr;       // attached to the completion of the latest bn_bwd_apply dispatch: the weight-gradient fork without a record of its own
+  std::vector<const float*> disp_cov; // gradient buffers whose producing apply carried ev_disp in this uwm_backward call (later dispatches cover earlier ones: in-order queue)
+  int disp_fork = 1;
   int use_side = 1;
   hipStream_t join_stream = nullptr;  // uwm_set_join_stream: stream that waits for the side stream at the end of uwm_backward (default: the caller's)
   bool packed_in_fwd = false;         // dgrad weight repacks were enqueued on the side stream by the last forward
@@ -124,6 +128,7 @@ struct uwm_model {
   int device = -1;                    // HIP device the bound arenas live on (uwm_bind)
   int nstages = 5;                    // backward stages = gradient buckets (head+decoder, then four encoder groups)
   bool hwq_warned = false;
+  ReduceQueue rq;                    // partial-sum reduces of the split weight gradients, flushed once per backward stage (uwm_kernels.h)
   std::vector<char> out_sums;        // per residual block: the BatchNorm-backward sums of its last BatchNorm were made by the dgrad that wrote its output gradient (run_dgrad bn_y)
 };
 
@@ -419,7 +424,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   }
   p.oh[m->head] = H; p.ow[m->head] = W;
   if (training) {
-    p.wg_part = alloc(wgrad_wino_scratch_floats());
+    p.wg_part = alloc(kWgParts * wgrad_wino_scratch_floats());      // several layers' partial images wait for one batched reduce
     // gradient buffers (same shapes as their activations)
     h = H / 2; w = W / 2;
     p.g[m->stem] = alloc((size_t)N * h * w * stemC);
@@ -575,12 +580,24 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
                    (double)cv.Cout * cv.Kpad);
   a.wino = c.m->plan.wino_mode + 1;
-  a.part = c.F(c.m->plan.wg_part); a.part_floats = wgrad_wino_scratch_floats();
-  if (c.wst && c.wst != c.st) {
-    // fork: the side stream must see everything enqueued so far on the main stream (dy, activations)
-    hipError_t e = hipEventRecord(c.m->ev_fork, c.st);
+  // partial images of a split launch: the next free slice of the scratch; their reduce is queued and runs with the other layers'
+  // in one launch (flush_reduces: when the scratch / queue fills up and at the end of every backward stage)
+  static const bool no_defer = dbg_flag("UWM_NO_DEFER_REDUCE");
+  ReduceQueue& rq = c.m->rq;
+  const size_t cap = wgrad_wino_scratch_floats();
+  if (rq.n + 1 >= ReduceQueue::kMax || rq.used_floats + cap > kWgParts * cap) {
+    hipError_t e = launch_wgrad_reduce_multi(rq, (c.wst && c.wst != c.st) ? c.wst : c.st);
     if (e != hipSuccess) return e;
-    e = hipStreamWaitEvent(c.wst, c.m->ev_fork, 0);
+  }
+  a.part = c.F(c.m->plan.wg_part) + rq.used_floats; a.part_floats = cap; a.rq = no_defer ? nullptr : &rq;
+  if (c.wst && c.wst != c.st) {
+    // fork: the side stream must see everything enqueued so far on the main stream (dy, activations).  Where dy came out of a
+    // bn_bwd_apply dispatch that carried ev_disp, that event IS the fork point
+    const bool covered = std::find(c.m->disp_cov.begin(), c.m->disp_cov.end(), dy) != c.m->disp_cov.end();
+    hipError_t e = hipSuccess;
+    if (!covered) e = hipEventRecord(c.m->ev_fork, c.st);
+    if (e != hipSuccess) return e;
+    e = hipStreamWaitEvent(c.wst, covered ? c.m->ev_disp : c.m->ev_fork, 0);
     if (e != hipSuccess) return e;
     return launch_wgrad(a, c.wst);
   }
@@ -604,12 +621,26 @@ static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, si
   uwm_model* m = c.m; const ConvL& cv = m->convs[ci]; const BNL& b = m->bns[cv.bn];
   const float* f = c.F(b.f_off); const float* y = c.F(m->plan.y[ci]);
   double* dg = c.D(b.d_off); double* db = c.D(b.d_off) + b.C;
-  // sums_fused: the dgrad that produced g left per-workgroup-replica partial sums behind (run_dgrad bn_fuse): add the replicas
-  hipError_t e = sums_fused ? launch_bn_bwd_fold(c.D(b.d_off) + 2 * b.C, b.nrep, 2 * b.C, b.C, dg, db, c.st)
-                            : launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
-  if (e != hipSuccess) return e;
-  return launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, dg, db, dy, m->grads + b.g_off, m->grads + b.b_off,
-                             npix, b.C, c.st);
+  // sums_fused: the dgrad that produced g left per-workgroup-replica partial sums behind (run_dgrad bn_fuse): the apply pass adds
+  // the replicas up in its own prologue (no fold launch between the dgrad and the apply)
+  hipEvent_t done = nullptr;
+  if (c.wst && c.wst != c.st && m->ev_disp && m->disp_fork) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c.st, &cs) != hipSuccess) { cs = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+    if (cs == hipStreamCaptureStatusNone) done = m->ev_disp;          // (a capturing stream takes the plain record / wait pair: graph edges)
+  }
+  hipError_t e = hipSuccess;
+  if (sums_fused)
+    e = launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, nullptr, nullptr, dy, m->grads + b.g_off, m->grads + b.b_off,
+                            npix, b.C, c.st, c.D(b.d_off) + 2 * b.C, b.nrep, 2 * b.C, done);
+  else {
+    e = launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
+    if (e != hipSuccess) return e;
+    e = launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, dg, db, dy, m->grads + b.g_off, m->grads + b.b_off,
+                            npix, b.C, c.st, nullptr, 0, 0, done);
+  }
+  if (e == hipSuccess && done) m->disp_cov.push_back(dy);
+  return e;
 }
 
 // BatchNorm backward of conv ci whose output went through swish [and the SE product]: g = grad wrt that activation
@@ -844,6 +875,8 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
 
   std::vector<char>& out_sums = m->out_sums;
   if (sb <= 0 || out_sums.size() != first_blk[3] + m->stages[3].size()) out_sums.assign(first_blk[3] + m->stages[3].size(), 0);
+  m->disp_cov.clear();
+  if (sb <= 0) m->rq = ReduceQueue();                   // (a failed earlier call may have left jobs behind)
   if (sb <= 0 && se > 0) {
     HIPCHK(hipMemsetAsync(m->grads, 0, (size_t)m->param_floats * sizeof(float), st));
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
@@ -1095,6 +1128,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
       LCHK(run_wgrad(c, m->stem, x4, nullptr, c.F(p.g[m->stem]), h1, w1));
     }
   }
+  LCHK(launch_wgrad_reduce_multi(m->rq, c.wst));      // the queued partial-sum reduces of these stages: one launch
   if (c.wst != st) {                    // join: the caller's stream waits for every wgrad of these stages
     HIPCHK(hipEventRecord(m->ev_join, c.wst));
     // data-parallel training hands in its communication stream: the bucket's all-reduce waits for this stage's weight
@@ -1130,6 +1164,7 @@ void uwm_destroy(uwm_handle h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
+  if (h->ev_disp) (void)hipEventDestroy(h->ev_disp);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
@@ -1171,19 +1206,27 @@ int uwm_bind(uwm_handle h, float* params, float* grads, float* buffers) {
     DeviceGuard g0(h->device);
     (void)hipStreamSynchronize(h->side);
     (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_pack);
+    if (h->ev_disp) (void)hipEventDestroy(h->ev_disp);
     (void)hipStreamDestroy(h->side);
-    h->side = nullptr; h->ev_fork = h->ev_join = h->ev_pack = nullptr; h->packed_in_fwd = false;
+    h->side = nullptr; h->ev_fork = h->ev_join = h->ev_pack = h->ev_disp = nullptr; h->packed_in_fwd = false;
   }
   h->device = dev;
   h->params = params; h->grads = grads; h->buffers = buffers;
   DeviceGuard guard(dev);
   if (h->use_side && !h->side) {        // created on the device the arenas live on
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; (void)hipGetLastError(); }
+    // LOWEST queue priority: the weight gradients are off the critical path, the dgrad / BatchNorm-backward chain on the caller's
+    // stream is it — when a CU slot frees up, the dependent chain's workgroups must get it first
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { prio_lo = 0; (void)hipGetLastError(); }
+    if (dbg_flag("UWM_SIDE_PRIO_NORMAL")) prio_lo = 0;
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo) != hipSuccess) { h->side = nullptr; (void)hipGetLastError(); }
     else if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming) != hipSuccess) {
       (void)hipStreamDestroy(h->side); h->side = nullptr; (void)hipGetLastError();
     }
+    if (h->side && hipEventCreate(&h->ev_disp) != hipSuccess) { h->ev_disp = nullptr; (void)hipGetLastError(); }
+    h->disp_fork = dbg_flag("UWM_NO_DISPATCH_FORK") ? 0 : 1;
     // ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order.  In a process that
     // has already created several streams (RCCL, torch) the side stream can alias the compute stream's queue: the
     // weight-gradient overlap is then silently lost (measured -5 %).  The variable is read when the HIP

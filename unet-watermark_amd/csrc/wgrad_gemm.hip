@@ -173,7 +173,7 @@ static hipError_t launch_wg(const WgradArgs& a0, hipStream_t st, int cls) {
   float* const out = nsplit > 1 ? a.part : a.dw;
   const size_t stride = nsplit > 1 ? image : 0;
   UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_gemm_kernel<TA, TB>), dim3((unsigned)(ntiles * nsplit)), dim3(256), lds, st, a, tilesB, ntiles, msplit, out, stride);
-  if (nsplit > 1) return launch_wgrad_reduce(a.part, nsplit, image / 4, a.dw, st);
+  if (nsplit > 1) return launch_wgrad_reduce(a.part, nsplit, image / 4, a.dw, st, a.rq);
   return hipGetLastError();
 }
 

@@ -557,8 +557,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st) {      // shared with wgrad_gemm.hip
+// the same reduce for every job of a queue in one launch: a workgroup finds its job by its block range
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceJobs jobs) {
+  __shared__ f4 red[8][32];
+  int k = 0;
+  while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const float* __restrict__ part = jobs.j[k].part; float* __restrict__ dw = jobs.j[k].dw;
+  const size_t n4 = jobs.j[k].n4; const int nsplit = jobs.j[k].nsplit;
+  const int u = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const size_t i = (size_t)(blockIdx.x - jobs.j[k].block0) * 32 + u;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int q = grp; q < nsplit; q += 8) s += *(const f4*)(part + ((size_t)q * n4 + i) * 4);
+  red[grp][u] = s;
+  __syncthreads();
+  if (grp == 0 && i < n4) {
+    f4 t = red[0][u];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][u];
+    *(f4*)(dw + i * 4) += t;
+  }
+}
+
+hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st, ReduceQueue* rq) {      // shared with wgrad_gemm.hip
+  if (rq) {
+    if (rq->n >= ReduceQueue::kMax) return hipErrorInvalidValue;       // the owner flushes before the queue is full
+    ReduceJob& j = rq->j[rq->n++];
+    j.part = part; j.dw = dw; j.n4 = n4; j.nsplit = nsplit; j.block0 = rq->blocks;
+    rq->blocks += (unsigned)((n4 + 31) / 32);
+    rq->used_floats += ((size_t)nsplit * n4 * 4 + 63) & ~(size_t)63;
+    return hipSuccess;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, part, nsplit, n4, dw);
+  return hipGetLastError();
+}
+hipError_t launch_wgrad_reduce_multi(ReduceQueue& q, hipStream_t st) {
+  if (q.n == 0) { q.used_floats = 0; q.blocks = 0; return hipSuccess; }
+  ReduceJobs jobs; jobs.n = q.n;
+  for (int i = 0; i < q.n; ++i) jobs.j[i] = q.j[i];
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(q.blocks), dim3(256), 0, st, jobs);
+  q.n = 0; q.blocks = 0; q.used_floats = 0;
   return hipGetLastError();
 }
 
@@ -589,8 +627,9 @@ static hipError_t launch_ww(const WgradArgs& a, hipStream_t st, int cls, int nbl
     UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_wino2_kernel<TA>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
   }
   if (a.nsplit > 1) {
-    const size_t n4 = (size_t)a.wrows * a.Kpad / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float*)a.part, a.nsplit, n4, a.dw);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_wgrad_reduce(a.part, a.nsplit, (size_t)a.wrows * a.Kpad / 4, a.dw, st, a.rq);
   }
   return hipGetLastError();
 }
