@@ -271,6 +271,8 @@ def main():
                          "(/root/reference/src/configs/unet_watermark_large.yaml:5-19,36) is --arch UnetPlusPlus --encoder resnet50 "
                          "--decoder-channels 1024,512,256,128,64 --size 1024 --batch 8")
     ap.add_argument("--no-ddp-check", action="store_true", help="skip the warm-up self-validation of the data-parallel exchange")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the train step from ONE captured hipGraph (Trainer(use_graph=True); single process only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce after the whole backward")
     ap.add_argument("--prof-steps", type=int, default=5, help="timed steps (the last ones) whose conv launches carry HIP event pairs")
@@ -313,7 +315,8 @@ def main():
     model = getattr(U, args.arch)(args.encoder, encoder_weights=None, in_channels=3, classes=1,
                                   **({"decoder_channels": dec} if dec else {})).to(dev)
     trainer = Trainer(model, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-4, weight_decay=1e-4,
-                      overlap_comm=not args.no_overlap, force_ddp=force_ddp and not os.environ.get("UWM_PG_ONLY"))
+                      overlap_comm=not args.no_overlap, force_ddp=force_ddp and not os.environ.get("UWM_PG_ONLY"),
+                      use_graph=args.graph and world == 1 and not force_ddp)
     g = torch.Generator(device="cpu").manual_seed(42 + rank)      # rank-distinct synthetic data
     n, s = args.batch, args.size
     x = torch.randn(n, 3, s, s, generator=g).to(dev)
@@ -343,6 +346,7 @@ def main():
     for i in range(args.steps):
         if i == args.steps - prof_steps:
             L.lib().uwm_prof_enable(1)
+            trainer.use_graph = False              # (profiled launches carry dispatch-attached events: eager steps)
         loss = trainer.step(x, t)
     barrier()
     dt = time.perf_counter() - t0
@@ -422,6 +426,7 @@ def main():
                        "decoder_channels": list(model.decoder_channels),
                        "grad_allreduce": ("rccl, 5 buckets overlapped with backward" if (world > 1 or force_ddp) else "none")},
             "loss": round(loss_val, 6),
+            "hipgraph_step": bool(trainer.use_graph and not trainer.ddp),
             "rccl_ranks": (dist.get_world_size() if (world > 1 or force_ddp) else 0),
             "ddp_check": ddp_check,
             "model_tflops": round(world * n * fwdbwd * args.steps / dt / 1e12, 2),

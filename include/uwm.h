@@ -144,6 +144,12 @@ int  uwm_adam(float* p, const float* g, float* m, float* v, long long n, float l
 int  uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, long long step, float grad_scale, float max_norm, void* scratch,
                    uwm_stream stream);
+/* The same update with every hyper-parameter in DEVICE memory, for a hipGraph-captured train step (one captured launch must
+ * serve every step): hyper = 10 floats {lr, beta1, beta2, eps, weight_decay, grad_scale, max_norm, step, -, -}; the call
+ * advances hyper[7] (the step count of the update it performs: write step - 1 there before the first call / after a restore)
+ * and fills the two bias-correction slots itself.  clip_scratch != NULL (>= 8 bytes): global-norm clipping to hyper[6]. */
+int  uwm_adam_graph(float* p, const float* g, float* m, float* v, long long n, float* hyper, void* clip_scratch,
+                    uwm_stream stream);
 /* torch.optim.SGD(lr, momentum, weight_decay) (coupled L2, dampening 0; the reference's OPTIMIZER.NAME == "SGD" branch,
  * /root/reference/src/train.py:272-278) over a flat range: buf = step == 1 ? g' : momentum*buf + g', p -= lr*buf with
  * g' = grad_scale*g + weight_decay*p; max_norm > 0 adds global-norm clipping as uwm_adam_clip (scratch >= 8 bytes). */

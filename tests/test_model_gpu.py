@@ -979,3 +979,47 @@ def test_fused_optimizer_releases_p_grad_with_its_lifetime(cuda):
     del opt2, opt; gc.collect()
     assert bwd()
     assert float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)) > 0
+
+
+def test_trainer_hipgraph_step_matches_eager(cuda):
+    """Trainer(use_graph=True): the whole train step (forward, Dice/BCE, staged backward with its weight-gradient side stream,
+    Adam with device-side hyper-parameters) captured once and replayed (SURVEY 8(e) "hipGraph the step") follows the eager
+    trainer step for step — same kernels, same order — including an LR change between replays and global-norm clipping."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd.train import Trainer
+    from oracle import unet_oracle as O
+    for enc, arch, clip in (("resnet18", "Unet", None), ("resnet18", "UnetPlusPlus", 0.5)):
+        torch.manual_seed(3)
+        a = getattr(U, arch)(enc).to(cuda)
+        b = getattr(U, arch)(enc).to(cuda)
+        b.load_state_dict(a.state_dict())
+        ta = Trainer(a, w_dice=0.5, w_bce=0.5, lr=1e-3, adam_eps=1e-2, max_grad_norm=clip)
+        tb = Trainer(b, w_dice=0.5, w_bce=0.5, lr=1e-3, adam_eps=1e-2, max_grad_norm=clip, use_graph=True)
+        for k in range(6):
+            x, t = O.synthetic_batch(4, 64, 96, seed=20 + k)
+            if k == 4:
+                for tr in (ta, tb):
+                    tr.opt.param_groups[0]["lr"] = 2.5e-4          # what ReduceLROnPlateau does between epochs
+            la = ta.step(x.to(cuda), t.to(cuda)).clone()
+            lb = tb.step(x.to(cuda), t.to(cuda)).clone()
+            # same kernels in the same order; the two runs still drift apart like any two fp32 runs of this net do (fp64-atomic
+            # BatchNorm sums land in a different order), at the rate the other multi-step trainer tests allow
+            assert torch.allclose(la, lb, rtol=0, atol=5e-4), (enc, arch, k, la, lb)
+        assert tb.opt._step == ta.opt._step == 6 and len(tb._graphs) == 1
+        d = (a.flat_parameters() - b.flat_parameters()).abs().max()
+        assert float(d) < 2e-3, float(d)
+        for (n1, r1), (_, r2) in zip(a.state_dict().items(), b.state_dict().items()):
+            if n1.endswith("running_var") or n1.endswith("num_batches_tracked"):
+                assert torch.allclose(r1.float(), r2.float(), rtol=1e-3, atol=1e-5), n1
+    # EfficientNet: the drop-connect draw is part of the captured step (device RNG), the step must train
+    torch.manual_seed(4)
+    m = U.Unet("efficientnet-b4").to(cuda)
+    tr = Trainer(m, lr=1e-3, use_graph=True)
+    x, t = O.synthetic_batch(2, 64, 64, seed=9)
+    x, t = x.to(cuda), t.to(cuda)
+    l0 = float(tr.step(x, t)[0])
+    rs = []
+    for _ in range(5):
+        l1 = float(tr.step(x, t)[0]); rs.append(m._rowscale.clone())
+    assert l1 == l1 and l1 < l0
+    assert any(not torch.equal(rs[0], r) for r in rs[1:])        # a fresh draw per replay

@@ -70,6 +70,7 @@ SIGNATURES = {
     "uwm_threshold": (I, [P, I, L, F, I, P, P]),
     "uwm_adam": (I, [P, P, P, P, L, F, F, F, F, F, L, F, P]),
     "uwm_adam_clip": (I, [P, P, P, P, L, F, F, F, F, F, L, F, F, P, P]),
+    "uwm_adam_graph": (I, [P, P, P, P, L, P, P, P]),
     "uwm_sgd": (I, [P, P, P, L, F, F, F, L, F, F, P, P]),
     "uwm_scale": (I, [P, L, F, P]),
     "uwm_set_winograd": (I, [I]),

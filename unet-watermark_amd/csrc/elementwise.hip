@@ -590,9 +590,19 @@ hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double*
 }
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam, coupled L2)
+// hyp != nullptr (hipGraph-captured train step, uwm_adam_graph): every hyper-parameter comes from DEVICE memory, so one captured
+// launch serves every step — hyp = {lr, beta1, beta2, eps, weight_decay, grad_scale, max_norm, step, bc1, sqrt(bc2)}; the
+// step counter and the two bias corrections are advanced by adam_hyper_kernel (one thread) in front of every adam launch
+__global__ void adam_hyper_kernel(float* hyp) {
+  const float step = hyp[7] + 1.f;
+  hyp[7] = step;
+  hyp[8] = 1.f - powf(hyp[1], step);
+  hyp[9] = sqrtf(1.f - powf(hyp[2], step));
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             size_t n4, size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2s,
-                            float gscale, const double* sumsq, float max_norm) {
+                            float gscale, const double* sumsq, float max_norm, const float* __restrict__ hyp) {
+  if (hyp) { lr = hyp[0]; b1 = hyp[1]; b2 = hyp[2]; eps = hyp[3]; wd = hyp[4]; gscale = hyp[5]; max_norm = hyp[6]; bc1 = hyp[8]; bc2s = hyp[9]; }
   if (sumsq) {   // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
     const float tn = (float)sqrt(*sumsq) * gscale;
     gscale *= fminf(1.f, max_norm / (tn + 1e-6f));
@@ -623,7 +633,14 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, f
                        float wd, float bc1, float bc2, float gscale, hipStream_t st, const double* sumsq, float max_norm) {
   const size_t n4 = (n + 3) / 4;
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, p, g, m, v, n4, n, lr, b1, b2, eps, wd, bc1,
-                     sqrtf(bc2), gscale, sumsq, max_norm);
+                     sqrtf(bc2), gscale, sumsq, max_norm, (const float*)nullptr);
+  return hipGetLastError();
+}
+hipError_t launch_adam_graph(float* p, const float* g, float* m, float* v, size_t n, float* hyp, const double* sumsq, hipStream_t st) {
+  const size_t n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, st, hyp);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n4, 256)), dim3(256), 0, st, p, g, m, v, n4, n, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f,
+                     sumsq, 0.f, (const float*)hyp);
   return hipGetLastError();
 }
 

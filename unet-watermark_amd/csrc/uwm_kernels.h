@@ -241,6 +241,7 @@ hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double*
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                        float eps, float wd, float bc1, float bc2, float gscale, hipStream_t st,
                        const double* sumsq = nullptr, float max_norm = 0.f);
+hipError_t launch_adam_graph(float* p, const float* g, float* m, float* v, size_t n, float* hyp /* device, 10 floats */, const double* sumsq, hipStream_t st);
 hipError_t launch_sumsq(const float* g, size_t n, double* out, hipStream_t st);
 hipError_t launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, float gscale,
                       hipStream_t st, const double* sumsq = nullptr, float max_norm = 0.f);

@@ -1355,6 +1355,12 @@ int uwm_adam_clip(float* p, const float* g, float* m, float* v, long long n, flo
   LCHK(launch_adam(p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream, (const double*)scratch, max_norm));
   return 0;
 }
+int uwm_adam_graph(float* p, const float* g, float* m, float* v, long long n, float* hyper, void* clip_scratch, uwm_stream stream) {
+  if (!p || !g || !m || !v || !hyper || n < 1) return fail("uwm_adam_graph: bad argument");
+  if (clip_scratch) LCHK(launch_sumsq(g, (size_t)n, (double*)clip_scratch, (hipStream_t)stream));
+  LCHK(launch_adam_graph(p, g, m, v, (size_t)n, hyper, (const double*)clip_scratch, (hipStream_t)stream));
+  return 0;
+}
 int uwm_sgd(float* p, const float* g, float* buf, long long n, float lr, float momentum, float wd, long long step, float gscale,
             float max_norm, void* scratch, uwm_stream stream) {
   if (!p || !g || !buf || n < 1 || step < 1 || (max_norm > 0.f && !scratch)) return fail("uwm_sgd: bad argument");

@@ -314,7 +314,10 @@ class Unet(nn.Module):
             self._rowscale = None
             L.check(L.lib().uwm_set_drop_connect(self._h, None))
             return
-        keep_prob = 1.0 - torch.tensor(self._mb_drop, dtype=torch.float32, device=device).view(-1, 1)
+        kp = getattr(self, "_keep_prob", None)
+        if kp is None or kp.device != device:           # (cached: a host-to-device copy has no place in a captured step)
+            kp = self._keep_prob = 1.0 - torch.tensor(self._mb_drop, dtype=torch.float32, device=device).view(-1, 1)
+        keep_prob = kp
         if self._keep_override is not None:
             keep = self._keep_override.to(device=device, dtype=torch.float32).reshape(self._n_mb, n)
         else:

@@ -216,6 +216,46 @@ class FusedAdam(_FusedFlatOptimizer):
     def _v(self):
         return self._bufs[1] if self._bufs else None
 
+    # ---- hipGraph-capturable form: every hyper-parameter (and the step count) lives in device memory
+    def _hyper_values(self, grad_scale: float):
+        g = self.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(grad_scale), float(self.max_grad_norm or 0.0))
+
+    def sync_hyper(self, grad_scale: float = 1.0):
+        """(Re)write the device-side hyper-parameter block of step_graph() from param_groups / the host step count.  Call
+        OUTSIDE a capture; needed only when something changed (an LR scheduler step, a restored checkpoint)."""
+        p = self.model.flat_parameters()
+        vals = self._hyper_values(grad_scale)
+        if getattr(self, "_hyper", None) is None or self._hyper.device != p.device:
+            self._hyper = torch.zeros(10, dtype=torch.float32, device=p.device)
+            self._hyper_host = None
+        want = vals + (float(self._step),)
+        if self._hyper_host != want:
+            self._hyper.copy_(torch.tensor(want + (0.0, 0.0), dtype=torch.float32))
+            self._hyper_host = want
+
+    @torch.no_grad()
+    def step_graph(self, grad_scale: float = 1.0):
+        """One Adam update through uwm_adam_graph: no host-side value enters the launch, so it can sit in a captured
+        hipGraph and be replayed for every step.  The caller mirrors the step count on the host (note_graph_step)."""
+        self._state_init()
+        self._check_frozen()
+        p = self.model.flat_parameters()
+        gr = self.model.flat_grads()
+        if getattr(self, "_hyper", None) is None:
+            raise RuntimeError("FusedAdam.step_graph: call sync_hyper() first (outside the capture)")
+        with L.on_device(p):
+            L.check(L.lib().uwm_adam_graph(C.c_void_p(p.data_ptr()), C.c_void_p(gr.data_ptr()), C.c_void_p(self._bufs[0].data_ptr()),
+                                           C.c_void_p(self._bufs[1].data_ptr()), p.numel(), C.c_void_p(self._hyper.data_ptr()),
+                                           self._clip_ptr(p), C.c_void_p(L.stream_ptr(p.device))))
+
+    def note_graph_step(self):
+        """Host mirror of the device step counter after one replay / eager step_graph()."""
+        self._step += 1
+        if getattr(self, "_hyper_host", None) is not None:
+            self._hyper_host = self._hyper_host[:-1] + (float(self._step),)
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = closure() if closure is not None else None
@@ -271,8 +311,14 @@ class Trainer:
     def __init__(self, model, w_dice: float = 1.0, w_bce: float = 0.0, smooth: float = 1e-5, eps: float = 1e-7,
                  lr: float = 1e-4, betas=(0.9, 0.999), adam_eps: float = 1e-8, weight_decay: float = 0.0,
                  group=None, overlap_comm: bool = True, force_ddp: bool = False, max_grad_norm=None,
-                 optimizer: str = "Adam", momentum: float = 0.9, global_dice: bool = False):
+                 optimizer: str = "Adam", momentum: float = 0.9, global_dice: bool = False, use_graph: bool = False):
         self.model = model
+        # use_graph: the whole step (forward, loss, staged backward with its weight-gradient side stream, Adam) is captured
+        # ONCE per batch shape into a hipGraph and replayed ("hipGraph the step"): the ~150-1200 launches of
+        # a step cost the host one graph launch.  Single-process Adam only; a data-parallel trainer keeps the eager path
+        # (its all-reduces are issued by torch.distributed between the backward stages).
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
         # global_dice (SURVEY.md 8(e) caveat): Dice is a ratio of batch sums, so DDP's mean of per-rank Dice losses is not the
         # Dice of the global batch.  With the flag the four loss sums (32 bytes) are all-reduced between the loss's two
         # halves and every rank back-propagates the GLOBAL loss: an N-rank run then optimises exactly what one process
@@ -307,6 +353,33 @@ class Trainer:
     def step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
         """images (N,C,H,W) fp32, masks (N,H,W)|(N,1,H,W) int64|uint8|float32 on the HIP device.
         Returns a device tensor {total, dice, bce} (no host sync)."""
+        if self.use_graph and not self.ddp and isinstance(self.opt, FusedAdam):
+            return self._step_graph(images, masks)
+        return self._step_eager(images, masks)
+
+    def _step_graph(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+        key = (tuple(images.shape), tuple(masks.shape), masks.dtype, images.device)
+        ent = self._graphs.get(key)
+        if ent is None:
+            # the first step of a shape runs eagerly (plans the workspace, sets kernel attributes, leaves no side-stream work
+            # un-joined), then the step is captured for the ones that follow — a capture executes nothing
+            out = self._step_eager(images, masks).clone()
+            gx, gt = images.clone(), masks.clone()
+            torch.cuda.synchronize(images.device)
+            self.opt.sync_hyper(1.0 / self.world)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._step_eager(gx, gt, graph_opt=True)
+            self._graphs[key] = (g, gx, gt, loss)
+            return out
+        g, gx, gt, loss = ent
+        self.opt.sync_hyper(1.0 / self.world)           # (a host compare; writes only after an LR change / restore)
+        gx.copy_(images); gt.copy_(masks)
+        g.replay()
+        self.opt.note_graph_step()
+        return loss
+
+    def _step_eager(self, images: torch.Tensor, masks: torch.Tensor, graph_opt: bool = False) -> torch.Tensor:
         m = self.model
         if not m.training:
             m.train()
@@ -351,7 +424,10 @@ class Trainer:
             self._reducer.finish()
         else:
             m._backward_raw(self._dl, 0, nst)
-        self.opt.step(grad_scale=1.0 / self.world)
+        if graph_opt:
+            self.opt.step_graph(grad_scale=1.0 / self.world)
+        else:
+            self.opt.step(grad_scale=1.0 / self.world)
         return self._loss
 
 
