@@ -883,11 +883,11 @@ def test_staged_backward_equals_whole_backward(cuda, enc, arch):
 
 @pytest.mark.parametrize("arch", ["Unet", "UnetPlusPlus"])
 def test_backward_is_bit_reproducible(cuda, arch):
-    """Round 2 replaced the float atomics of the weight-gradient kernels on the headline path (Winograd-domain, 16-channel,
-    head, sub-pixel up2) by per-split / per-workgroup partial sums added in a fixed order: two backward passes over the same
-    forward must give BIT-IDENTICAL gradients for every 3x3 / stride-1 convolution (VERDICT r01 'deterministic-gradient
-    mode').  The flattened implicit-GEMM weight gradients (stride-2, 1x1 downsample, 7x7 stem) still use float atomics and the
-    BatchNorm sums fp64 atomics: those tensors are held to rounding (1e-5 relative)."""
+    """No float atomics are left on the gradient paths of the ResNet models: the Winograd-domain, 16-channel, head, sub-pixel
+    up2, stem and (round 3) flattened implicit-GEMM weight gradients (stride-2 3x3, 1x1 downsample) all sum per-split /
+    per-workgroup partials in a fixed order, the head-bias column sum is two-stage.  Two backward passes over the same forward
+    give a BIT-IDENTICAL gradient ARENA ("assert the WHOLE arena torch.equal").  BatchNorm gamma / beta
+    gradients are fp64-atomic sums cast to fp32: their order noise is 1e-16 relative, below one fp32 ulp."""
     import unet_watermark_amd as U
     from oracle import unet_oracle as O
     torch.manual_seed(11)
@@ -899,26 +899,18 @@ def test_backward_is_bit_reproducible(cuda, arch):
     dl = torch.zeros_like(logits)
     dl[..., 0] = torch.randn(logits.shape[:-1], device=cuda, generator=torch.Generator(device="cuda").manual_seed(2)) * 1e-3
     runs = []
-    for _ in range(2):
+    for _ in range(3):
         m._backward_raw(dl)
         torch.cuda.synchronize()
         runs.append(m.flat_grads().clone())
-    a, b = runs
-    exact = loose = 0
+    a, b, c = runs
     for name, kind, arena, off, shp, strd in m._infos:
         if arena != 0:
             continue
-        va, vb = a.as_strided(shp, strd, off), b.as_strided(shp, strd, off)
-        # resnet34: every 3x3 conv is stride 1 except the first conv of layer2/3/4's first block (the stem is 7x7, downsamples 1x1)
-        stride1_3x3 = len(shp) == 4 and shp[2] == 3 and shp[3] == 3 and re.search(r"encoder\.layer[234]\.0\.conv1\.weight$", name) is None
-        if stride1_3x3:
-            assert torch.equal(va, vb), f"{name}: weight gradient differs between two backward passes"
-            exact += 1
-        else:
-            d = float((va.double() - vb.double()).norm()); nrm = float(va.double().norm())
-            assert d <= 1e-5 * nrm + 1e-12, f"{name}: {d / max(nrm, 1e-30):.2e}"
-            loose += 1
-    assert exact >= 40 and loose > 0
+        va, vb, vc = (r.as_strided(shp, strd, off) for r in (a, b, c))
+        assert float(va.abs().max()) > 0, name
+        assert torch.equal(va, vb) and torch.equal(va, vc), f"{name}: gradient differs between backward passes over the same forward"
+    assert torch.equal(a, b) and torch.equal(a, c)      # the whole arena, padding included
 
 
 def test_fused_sgd_resumes_torch_sgd_momentum(cuda):

@@ -563,7 +563,9 @@ hipError_t launch_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int 
 }
 
 // ------------------------------------------------------------------ per-channel column sum (bias gradient)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, size_t npix, int C, float* out) {
+// Two stages, no float atomics (bit-reproducible): a workgroup stores ONE fp64 partial per channel into scratch[block][C];
+// colsum_finish_kernel adds the partials in block order.  (scratch == nullptr: the single-launch form with float atomics.)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, size_t npix, int C, float* out, double* scratch) {
   __shared__ float red[256 * 4];
   const int tc = C / 4, tr = 256 / tc;
   const int cx = threadIdx.x % tc, rx = threadIdx.x / tc;
@@ -577,15 +579,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
     const int q = threadIdx.x / 4, e = threadIdx.x % 4;
     double acc = 0.0;
     for (int k = 0; k < tr; ++k) acc += (double)red[(k * tc + q) * 4 + e];
-    atomicAdd(out + threadIdx.x, (float)acc);
+    if (scratch) scratch[(size_t)blockIdx.x * C + threadIdx.x] = acc;
+    else atomicAdd(out + threadIdx.x, (float)acc);
   }
 }
-hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double*, hipStream_t st) {
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ scratch, int nparts, int C, float* out) {
+  // thread (channel c, group g of G = 256 / C): partials g, g + G, ... (independent loads), then the G group sums in group order
+  __shared__ double red[256];
+  const int G = 256 / C, c = threadIdx.x % C, g = threadIdx.x / C;
+  double acc = 0.0;
+  if (g < G)
+    for (int k = g; k < nparts; k += G) acc += scratch[(size_t)k * C + c];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    double t = red[threadIdx.x];
+    for (int k = 1; k < G; ++k) t += red[k * C + threadIdx.x];
+    out[threadIdx.x] += (float)t;
+  }
+}
+size_t colsum_scratch_doubles(int C) { return (size_t)256 * C; }
+hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double* scratch, hipStream_t st) {
   if ((C & 3) || C > 256 || (256 % (C / 4))) return hipErrorInvalidValue;
   const int tr = 256 / (C / 4);
   unsigned nb = nblocks(npix, tr * 16);
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, g, npix, C, out);
+  if (nb > (scratch ? 256u : 1024u)) nb = scratch ? 256u : 1024u;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, g, npix, C, out, scratch);
+  if (scratch) hipLaunchKernelGGL(colsum_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)scratch, (int)nb, C, out);
   return hipGetLastError();
 }
 

@@ -237,7 +237,8 @@ hipError_t launch_split_accum(const float* gcat, int Cc, int off, int C, size_t 
                               const float* mscale, const float* mshift, int accumulate, hipStream_t st);
 hipError_t launch_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD,
                              int CoutP, hipStream_t st);
-hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double* scratch, hipStream_t st);
+hipError_t launch_colsum(const float* g, size_t npix, int C, float* out, double* scratch, hipStream_t st);   // out[c] += sum over pixels; scratch (colsum_scratch_doubles(C)): two-stage, fixed order; nullptr: float atomics
+size_t colsum_scratch_doubles(int C);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                        float eps, float wd, float bc1, float bc2, float gscale, hipStream_t st,
                        const double* sumsq = nullptr, float max_norm = 0.f);

@@ -88,6 +88,7 @@ struct Plan {                       // workspace layout for one (N,H,W,training)
   std::vector<size_t> cat;          // UnetPlusPlus: per node, materialised skip concat (0 = none)
   size_t gcat = 0;                  // UnetPlusPlus: shared scratch for a node's skip-concat gradient
   size_t stat_d = 0, stat_d_count = 0;   // BN double region
+  size_t colsum_scr = 0;            // per-workgroup fp64 partials of the head-bias gradient (two-stage, fixed order), in floats
   size_t wg_part = 0;               // per-split partial sums of the Winograd weight gradient (deterministic two-stage reduce)
 };
 
@@ -424,6 +425,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   }
   p.oh[m->head] = H; p.ow[m->head] = W;
   if (training) {
+    p.colsum_scr = alloc(2 * colsum_scratch_doubles(m->CP));
     p.wg_part = alloc(kWgParts * wgrad_wino_scratch_floats());      // several layers' partial images wait for one batched reduce
     // gradient buffers (same shapes as their activations)
     h = H / 2; w = W / 2;
@@ -900,7 +902,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     const int last_c2 = m->nodes.empty() ? m->dec.back().c2 : m->nodes.back().c2;
     Src d4 = lazy_src(c, last_c2, H, W);
     LCHK(run_wgrad(c, m->head, d4, nullptr, dlogits, H, W));
-    LCHK(launch_colsum(dlogits, (size_t)N * H * W, hd.CoutP, m->grads + hd.bias_off, nullptr, st));
+    LCHK(launch_colsum(dlogits, (size_t)N * H * W, hd.CoutP, m->grads + hd.bias_off, (double*)c.F(p.colsum_scr), st));
     bool head_sums = false;                               // BatchNorm-backward sums of the last decoder conv, made by the head's dgrad
     LCHK(run_dgrad(c, m->head, dlogits, H, W, H, W, c.F(p.g[last_c2]), nullptr, d4.ptr, d4.scale, d4.shift, nullptr,
                    m->convs[last_c2].bn, &head_sums));

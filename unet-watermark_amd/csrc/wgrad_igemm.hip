@@ -7,8 +7,10 @@
 // fragments are read with ds_read_b32 (row stride == 16 mod 32 floats: conflict-free).
 // X is gathered with the same lazy BatchNorm+ReLU / upsample / concat transform as the forward
 // kernel; each thread's k-column (hence tap, channel, source, scale, shift) is fixed for the
-// whole pixel loop.  The pixel range is split over `nsplit` workgroups per output tile and the
-// partial tiles are combined with fp32 atomics into a pre-zeroed dW.
+// whole pixel loop.  The pixel range is split over `nsplit` workgroups per output tile; every split
+// stores its own dW-shaped partial image (plain stores) and wgrad_reduce_kernel (wgrad_wino.hip) adds the
+// images in a fixed order — no float atomics: the gradient is bit-reproducible (round 3; the atomics also
+// cost 1.76x the algorithmic HBM traffic).  nsplit == 1 adds straight into the pre-zeroed dW.
 //
 // Replaces the weight-gradient half of autograd's conv2d backward.
 #include "uwm_kernels.h"
@@ -190,7 +192,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = a0 + wa * (TA / WA) + i * 16 + lq * 4 + e;
-        if (row < a.wrows && kc < a.Kpad) atomicAdd(a.dw + (size_t)row * a.Kpad + kc, acc[i][j][e]);
+        if (row < a.wrows && kc < a.Kpad) {
+          if (a.nsplit > 1) a.part[((size_t)split * a.wrows + row) * a.Kpad + kc] = acc[i][j][e];      // this split's partial image
+          else a.dw[(size_t)row * a.Kpad + kc] += acc[i][j][e];                                       // the only writer of this element
+        }
       }
     }
 }
@@ -202,6 +207,11 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
   static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
   { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_igemm_kernel<TA, TB, WA, WB>, lds); if (e != hipSuccess) return e; }
   UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_igemm_kernel<TA, TB, WA, WB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
+  if (a.nsplit > 1) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_wgrad_reduce(a.part, a.nsplit, (size_t)a.wrows * a.Kpad / 4, a.dw, st, a.rq);
+  }
   return hipGetLastError();
 }
 
@@ -246,10 +256,13 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
     }
   }
   const int tiles = ((a.wrows + TA - 1) / TA) * ((a.Kpad + TB - 1) / TB);
-  // aim for ~1024 workgroups, at least 256 pixels (8 steps) per split
+  // aim for ~1024 workgroups, at least 256 pixels (8 steps) per split; every split owns a partial image in the scratch
   int nsplit = (1024 + tiles - 1) / tiles;
   int maxsplit = (a.M + 255) / 256;
   if (nsplit > maxsplit) nsplit = maxsplit;
+  const size_t image = (size_t)a.wrows * a.Kpad;
+  if (nsplit > 1 && (!a.part || a.part_floats < 2 * image)) { a.part = wgrad_op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); a.rq = nullptr; }      // single-operator entry points
+  if (nsplit > 1 && (!a.part || (size_t)nsplit * image > a.part_floats)) nsplit = a.part ? (int)(a.part_floats / image) : 1;
   if (nsplit < 1) nsplit = 1;
   int msplit = (a.M + nsplit - 1) / nsplit;
   msplit = (msplit + 31) & ~31;
