@@ -49,7 +49,7 @@ enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* 
 enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
        UWM_KIND_BN_MEAN = 4, UWM_KIND_BN_VAR = 5 };
 enum { UWM_ARENA_PARAM = 0, UWM_ARENA_BUFFER = 1 };
-enum { UWM_PREC_F32 = 0, UWM_PREC_BF16X3 = 1, UWM_PREC_BF16X3_ALL = 2 };       /* uwm_set_precision */
+enum { UWM_PREC_F32 = 0, UWM_PREC_BF16X3 = 1, UWM_PREC_BF16X3_ALL = 2, UWM_PREC_F16X3 = 3, UWM_PREC_F16X3_ALL = 4 };       /* uwm_set_precision */
 
 /* mirrors smp.Unet(encoder_name, encoder_depth=5, decoder_channels, in_channels, classes) */
 typedef struct {
@@ -199,7 +199,13 @@ int  uwm_get_winograd_mode(uwm_handle h);
  *   UWM_PREC_BF16X3_ALL  forward products of those layers as well.  Measured logit error vs the fp32 CPU reference:
  *                        < 1e-3 on resnet18 / efficientnet-b4, 1.6e-3 on resnet34 (2x256x192) — outside BASELINE's bar on
  *                        the deeper encoders, offered for what the reference itself does on a GPU: reduced-precision
- *                        training (fp16 autocast + GradScaler, /root/reference/src/train.py:75,89-98). */
+ *                        training (fp16 autocast + GradScaler, /root/reference/src/train.py:75,89-98).
+ * "fp16x3" arithmetic (conv_f16x3.hip) is the same three-term product over FP16 halves (hi = fp16(x), lo = fp16(x - hi): 22
+ * mantissa bits per operand, relative error 2^-22 per product against 2^-24 for fp32) on gfx950's
+ * v_mfma_f32_16x16x32_f16, direct-form convolution, fp32 accumulation; fp16's exponent range is covered by exact
+ * power-of-two scaling of every filter row (and of a dgrad's dY).  fp32-class accuracy: it meets the fp32 mode's bars.
+ *   UWM_PREC_F16X3       the FORWARD products of the 3x3 stride-1 layers with channels % 32 == 0
+ *   UWM_PREC_F16X3_ALL   their data-gradient products as well (the layers whose dgrad has the plain epilogue) */
 int  uwm_set_precision(uwm_handle h, int mode);
 int  uwm_get_precision(uwm_handle h);
 /* EfficientNet encoders only: stochastic depth ("drop connect") of the MBConv blocks in training mode.  `rowscale` is a

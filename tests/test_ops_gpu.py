@@ -741,3 +741,72 @@ def test_depthwise_conv_forward_dgrad_wgrad(cuda, shape):
     assert (dx.cpu() - ref_dx).abs().max() < 2e-5 * max(1.0, float(ref_dx.abs().max()))
     ref_dw = wt.grad.reshape(c, k * k).t() + dw0
     assert (dw.cpu() - ref_dw).abs().max() < 5e-5 * max(1.0, float(ref_dw.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 64, 64, 24, 40),       # layer1-like, partial 16x16 tiles in both directions
+    (1, 32, 128, 16, 16),      # one chunk pair, two channel tiles
+    (2, 128, 96, 8, 16),       # minimum tile height; Cout 96 over-hangs the 64-channel tile
+    (1, 256, 256, 32, 32),     # deep stage
+])
+def test_conv_f16x3_direct(cuda, shape):
+    """conv_f16x3.hip (cfg 600): direct 3x3 on v_mfma_f32_16x16x32_f16 with every operand split into two fp16 halves and
+    row-scaled filters — the fp32 bars of _conv_case (2e-5 of the output range, BatchNorm statistics 1e-5), plain and with the
+    lazy BatchNorm + ReLU input transform."""
+    n, cin, cout, h, w = shape
+    _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=600)
+    _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=600, lazy=True, seed=5)
+
+
+def test_conv_f16x3_error_vs_fp64_and_range(cuda):
+    """fp16x3 keeps 22 mantissa bits per operand: against an fp64 convolution its error must stay within 4x the exact-fp32
+    direct kernel's (the bf16x3 kernel's is ~30x) — and that must hold when the operands sit far from fp16's comfortable range:
+    tiny filters (1e-6: scaled up row by row), rows of very different magnitude, large activations.  Activations are NOT
+    scaled (a power of two that is safe for every input does not exist without a pass over the tensor): below the fp16
+    normal range the low half is a subnormal with an absolute step of 2^-24, so a tensor whose values are all tiny keeps an
+    absolute error of ~3e-8 per element — 3e-8 / |x| relative (last case; unit-scale activations behind a BatchNorm: the fp32 level)."""
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, h, w = 2, 128, 64, 32, 32
+    for xmag, wmag in ((1.0, 1.0), (300.0, 1e-6), (0.25, 3.0), (1e-3, 20.0)):
+        x = torch.randn(n, cin, h, w, generator=g) * xmag
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (wmag / (cin * 9) ** 0.5)
+        wt[5] *= 1e-4; wt[7] *= 1e3                      # rows of very different magnitude: each has its own scale
+        ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+        xd = nhwc(x).to(cuda)
+        wp, kpad = pack_w(wt)
+        wp = wp.to(cuda)
+        errs = {}
+        for name, cfg in (("f16x3", 600), ("direct", 164)):
+            y = torch.empty(n, h, w, cout, device=cuda)
+            s0 = src(xd)
+            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), cout, kpad, 3, 3, 1, 1, n, cout, None, P(y), None, cfg, stream()))
+            torch.cuda.synchronize()
+            d = (nchw(y.cpu()).double() - ref).abs()
+            errs[name] = float((d / ref.abs().amax((0, 2, 3), keepdim=True)).max())       # relative to each output channel's range
+        bound = 4 * errs["direct"] + 1e-7 if xmag >= 0.25 else 4e-8 / xmag
+        assert errs["f16x3"] < bound and errs["f16x3"] < 5e-5, (xmag, wmag, errs)
+
+
+def test_conv_f16x3_upsample_concat(cuda):
+    """decoder conv1 on the fp16x3 kernel: cat(nearest_x2(d), skip), both sources lazy, concat boundary on a 16-channel chunk."""
+    L = lib()
+    g = torch.Generator().manual_seed(1)
+    n, c0, c1, cout, h, w = 2, 48, 16, 64, 8, 12
+    d = torch.randn(n, c0, h, w, generator=g)
+    sk = torch.randn(n, c1, 2 * h, 2 * w, generator=g)
+    sc0, sh0 = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    sc1, sh1 = torch.rand(c1, generator=g) + 0.5, torch.randn(c1, generator=g) * 0.2
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
+    a0 = torch.relu(d * sc0[:, None, None] + sh0[:, None, None])
+    a1 = torch.relu(sk * sc1[:, None, None] + sh1[:, None, None])
+    ref = F.conv2d(torch.cat([F.interpolate(a0, scale_factor=2, mode="nearest"), a1], 1), wt, None, 1, 1)
+    dd, skd = nhwc(d).to(cuda), nhwc(sk).to(cuda)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(cuda)
+    t = [sc0.to(cuda), sh0.to(cuda), sc1.to(cuda), sh1.to(cuda)]
+    y = torch.empty(n, 2 * h, 2 * w, cout, device=cuda)
+    s0, s1 = src(dd, t[0], t[1], relu=1, up=1), src(skd, t[2], t[3], relu=1)
+    L.check(L.lib().uwm_op_conv(C.byref(s0), C.byref(s1), P(wp), cout, kpad, 3, 3, 1, 1, n, cout, None, P(y), None, 600, stream()))
+    torch.cuda.synchronize()
+    assert (nchw(y.cpu()) - ref).abs().max() < 2e-5 * float(ref.abs().max())

@@ -18,7 +18,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "conv_wino_x3.hip", "conv_up2.hip", "conv_gemm.hip", "conv_head.hip", "mbconv.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "wgrad_c16.hip", "wgrad_gemm.hip", "wgrad_stem.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "conv_wino_x3.hip", "conv_f16x3.hip", "conv_up2.hip", "conv_gemm.hip", "conv_head.hip", "mbconv.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "wgrad_c16.hip", "wgrad_gemm.hip", "wgrad_stem.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
 
 
@@ -41,7 +41,7 @@ KIND_CONV_W, KIND_BIAS, KIND_BN_GAMMA, KIND_BN_BETA, KIND_BN_MEAN, KIND_BN_VAR =
 ARENA_PARAM, ARENA_BUFFER = 0, 1
 ENC = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "efficientnet-b4": 104}
 ARCH = {"Unet": 0, "UnetPlusPlus": 1}
-PREC = {"f32": 0, "bf16x3": 1, "bf16x3_all": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16x3_all": 2, "f16x3": 3, "f16x3_all": 4}
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 # every symbol include/uwm.h declares: (restype, argtypes)

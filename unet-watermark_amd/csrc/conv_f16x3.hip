@@ -1,0 +1,377 @@
+// fp16x3 direct 3x3 / stride-1 convolution (forward AND dgrad) for gfx950 on v_mfma_f32_16x16x32_f16 — the CDNA4 half-precision
+// matrix instruction, 16x the rate of the fp32 one — with fp32-class accuracy:
+//
+//   every fp32 operand is split ONCE, when it is staged, into two fp16 halves  x = hi + lo  (hi = fp16(x), lo = fp16(x - hi):
+//   22 mantissa bits together) and a product is formed as  hi*hi' + hi*lo' + lo*hi'  with fp32 accumulation inside the MFMA:
+//   relative error 2^-22 per product (the dropped lo*lo' term), against 2^-24 for an fp32 multiply — measured per layer in
+//   tests/test_ops_gpu.py.  (The bf16x3 mode of conv_wino_x3.hip keeps 16 bits: 2^-16, which is what pushed its forward
+//   outside the 1e-3 logit bar.)  fp16's narrow EXPONENT is handled by exact power-of-two scaling: every filter row is scaled so
+//   that its largest tap lands in [2^13, 2^14) (f16x3_rowscale_kernel; undone in the epilogue), a dgrad's dY by a per-tensor
+//   power of two (ConvArgs::xscale); activations (O(1) behind a BatchNorm) are taken as they are and clamped to +-65504.
+//
+// Direct form, not Winograd: 3 half-precision MFMAs per 32 products at 16x the fp32 rate is 2.4x the fp32-Winograd MFMA
+// floor, and the kernel has no transforms to pay — the workgroup is bound by staging (HBM / LDS), not by the matrix pipe.
+//
+// Work split: workgroup = 16x16 output pixels x 64 output channels, 4 waves, wave w = pixel rows 4w .. 4w+3 (4 pixel fragments)
+// x 4 channel fragments = 16 accumulator tiles (64 VGPRs).  K runs over 16-channel chunks x 5 tap pairs (tap slots 0..9, slot 9
+// is zero padding): lane group g = lane >> 4 of an MFMA takes tap slot 2*ks + (g >> 1), channels 8*(g & 1) .. +7.
+//   * the 18x18 halo patch of a chunk goes to LDS through registers (lazy BatchNorm + ReLU, nearest x2 upsample, channel concat,
+//     zero padding and the hi / lo split applied while staging; 80 bytes per pixel: [hi 16 ch | lo 16 ch | pad] — the pad makes
+//     the 16 pixel rows of a ds_read_b128 fragment read conflict-free), double-buffered, one barrier per chunk;
+//   * the filter fragments come straight from global memory / L2 in MFMA lane order (f16x3_weights_multi_kernel packs
+//     [chunk][tap pair][channel fragment][hi | lo][lane][8 halfs] once per step), one 16-byte load per lane and fragment,
+//     prefetched one tap pair ahead in registers: no LDS traffic, no barrier for the weights;
+//   * weights are the A operand (rows = output channels), pixels the B operand, so a lane ends with 4 consecutive output
+//     channels of one pixel: one 16-byte NHWC store.  Epilogue contract of conv_wino_kernel's plain form: row un-scale, bias,
+//     residual addend, ReLU mask, BatchNorm statistics / fused BatchNorm-backward sums (bnb_*, bnb_y).
+//
+// Reference semantics replaced: the 3x3 convolutions of smp.Unet's encoder / decoder forward and their input gradients
+// (/root/reference/src/models/unet_model.py:64-71 -> SURVEY.md §8 a5-a8, a10, a14).
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#ifndef UWM_F16_ABL
+#define UWM_F16_ABL 0       // compile-time timing ablations (scripts/ablate_f16x3.sh): 1 no MFMA, 2 no filter loads, 4 no pixel-fragment LDS reads, 8 no patch loads / stores, 16 no epilogue; 0 in the product build
+#endif
+constexpr int kFT = 16, kFP = kFT + 2, kFPP = kFP * kFP;      // 16x16 output pixels, 18x18 = 324 patch pixels
+constexpr int kFPix = 40;                                      // halfs per patch pixel: 16 hi + 16 lo + 8 pad (80 bytes)
+constexpr int kFBuf = kFPP * kFPix;                            // halfs per patch buffer (25 920 bytes)
+constexpr int kFKs = 5;                                        // tap pairs per chunk (10 tap slots, the last one zero)
+constexpr int kFRounds = (kFPP * 4 + 255) / 256;               // 16-byte units of a chunk (324 px x 4) over 256 threads: 6 rounds
+
+// ---------------------------------------------------------------- filter bank
+// bank = [C/16 chunks][5 tap pairs][nJ fragments][2 planes][64 lanes][8 halfs] halfs, then float rinv[nJ*16] (1 / row scale).
+// rows are padded to whole 64-row tiles with zeros.  mode 0: rows x [tap][chans] forward weights (k = tap*chans + c);
+// mode 2: the dgrad bank straight from the FORWARD weights: rows = input channels, chans = output channels,
+// g'[tap][ch] = w[ch][8 - tap][row] (transposed + mirrored).
+__host__ __device__ inline int f16x3_nj_(int rows) { return ((rows + 63) / 64) * 4; }
+int f16x3_nj(int rows) { return f16x3_nj_(rows); }
+size_t f16x3_bank_floats(int rows, int chans) {          // in floats (the model's workspace unit)
+  const size_t halfs = (size_t)(chans / 16) * kFKs * f16x3_nj(rows) * 2 * 64 * 8;
+  return halfs / 2 + (size_t)f16x3_nj(rows) * 16;
+}
+static inline __host__ __device__ size_t f16x3_rinv_off_floats(int rows, int chans) { return (size_t)(chans / 16) * 5 * (size_t)(((rows + 63) / 64) * 4) * 512; }
+size_t f16x3_rinv_off(int rows, int chans) { return f16x3_rinv_off_floats(rows, chans); }
+
+__device__ __forceinline__ float f16x3_wval(const WinoJob& jb, int row, int slot, int ch) {
+  if (row >= jb.rows || slot >= 9 || ch >= jb.chans) return 0.f;
+  if (jb.mode == 0) return jb.w[(size_t)row * jb.Kpad + (size_t)slot * jb.chans + ch];
+  return ch < jb.src_rows ? jb.w[(size_t)ch * jb.Kpad + (size_t)(8 - slot) * jb.rows + row] : 0.f;
+}
+// one wave per filter row: s = 2^(14 - e) for row max = m * 2^e (m in [0.5, 1)): the largest tap lands in [2^13, 2^14)
+__global__ __launch_bounds__(256) void f16x3_rowscale_kernel(const WinoJobs jobs) {
+  const WinoJob jb = jobs.j[blockIdx.y];
+  const int nJ = f16x3_nj_(jb.rows);
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= nJ * 16) return;
+  float mx = 0.f;
+  if (row < jb.rows)
+    for (int i = lane; i < 9 * jb.chans; i += 64) mx = fmaxf(mx, fabsf(f16x3_wval(jb, row, i / jb.chans, i % jb.chans)));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if (lane == 0) {
+    float s = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); s = ldexpf(1.f, 14 - e); }
+    float* rinv = jb.ut + f16x3_rinv_off_floats(jb.rows, jb.chans);
+    rinv[row] = 1.f / s;                             // (exact: a power of two)
+  }
+}
+__global__ __launch_bounds__(256) void f16x3_weights_multi_kernel(const WinoJobs jobs) {
+  const WinoJob jb = jobs.j[blockIdx.y];
+  const int nJ = f16x3_nj_(jb.rows);
+  const size_t total = (size_t)(jb.chans / 16) * kFKs * nJ * 64;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const int j = (int)((i >> 6) % nJ);
+  const int t = (int)((i >> 6) / nJ);                 // chunk * 5 + ks
+  const int ks = t % kFKs, chunk = t / kFKs;
+  const int row = j * 16 + (lane & 15), g = lane >> 4;
+  const int slot = 2 * ks + (g >> 1), ch0 = chunk * 16 + 8 * (g & 1);
+  const float* rinv = jb.ut + f16x3_rinv_off_floats(jb.rows, jb.chans);
+  const float s = 1.f / rinv[row];
+  h8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = f16x3_wval(jb, row, slot, ch0 + e) * s;
+    const _Float16 h = (_Float16)v;
+    hi[e] = h; lo[e] = (_Float16)(v - (float)h);
+  }
+  _Float16* bank = (_Float16*)jb.ut;
+  h8* dst = (h8*)(bank + ((size_t)t * nJ + j) * 1024 + lane * 8);
+  dst[0] = hi;
+  dst[64] = lo;                                       // plane 1: +512 halfs
+}
+hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st) {
+  if (jobs.n <= 0) return hipSuccess;
+  size_t mx = 0; int mr = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    if (jobs.j[i].chans & 15) return hipErrorInvalidValue;
+    const size_t t = (size_t)(jobs.j[i].chans / 16) * kFKs * f16x3_nj(jobs.j[i].rows) * 64;
+    if (t > mx) mx = t;
+    if (f16x3_nj(jobs.j[i].rows) * 16 > mr) mr = f16x3_nj(jobs.j[i].rows) * 16;
+  }
+  hipLaunchKernelGGL(f16x3_rowscale_kernel, dim3((unsigned)((mr + 3) / 4), (unsigned)jobs.n), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(f16x3_weights_multi_kernel, dim3((unsigned)((mx + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- main kernel
+__device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];      // [2][324 px][40 halfs]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px16 = lane & 15, g = lane >> 4;
+
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesN = (a.Cout + 63) / 64;
+  const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
+  const int tn = tile % tilesN; tile /= tilesN;
+  const int tw = tile % tilesW; tile /= tilesW;
+  const int th = tile % tilesH; const int n = tile / tilesH;
+  const int n0 = tn * 64, h0 = th * kFT, w0 = tw * kFT;
+  const int nJ = a.wu_ncb;
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- patch staging through registers: 1296 16-byte units (pixel, channel quad) = 6 rounds; a round's geometry is one packed
+  // word (clamped row, clamped column, in-bounds bit) — the source offset is rebuilt from it per chunk (the two sources of a
+  // concat differ in size when one of them is up-sampled)
+  unsigned geo[kFRounds];
+#pragma unroll
+  for (int rd = 0; rd < kFRounds; ++rd) {
+    const int u = rd * 256 + tid;
+    const bool act = u < kFPP * 4;
+    const int pp = act ? (u >> 2) : 0;
+    const int py = pp / kFP, pxx = pp - py * kFP;
+    const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
+    const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+    const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+    geo[rd] = ((unsigned)hc << 16) | (unsigned)wc | (ok ? 0x80000000u : 0u) | (act ? 0x00008000u : 0u);
+  }
+  const float xs = a.xscale ? *a.xscale : 1.f;          // dgrad: power-of-two scale of dY (1 for activations)
+  f4 pv[kFRounds], psc, psh; int prelu = 0; bool phas = false;
+  auto patch_load = [&](int cc) {
+    const int c = cc * 16;
+    const bool first = c < a.C0;
+    const Src& s = first ? a.s0 : a.s1;
+    prelu = s.relu;
+    const int cl = (first ? c : c - a.C0) + (tid & 3) * 4;
+    phas = s.scale != nullptr;
+    if (phas) { psc = *(const f4*)(s.scale + cl); psh = *(const f4*)(s.shift + cl); }
+    const float* sp = s.ptr + cl;
+#pragma unroll
+    for (int rd = 0; rd < kFRounds; ++rd) {
+      const int hc = (int)((geo[rd] >> 16) & 0x7fffu), wc = (int)(geo[rd] & 0x7fffu);
+      const size_t off = (((size_t)n * s.H + (hc >> s.up)) * s.W + (wc >> s.up)) * s.C;
+      pv[rd] = *(const f4*)(sp + off);
+    }
+  };
+  auto patch_store = [&](int buf) {
+#pragma unroll
+    for (int rd = 0; rd < kFRounds; ++rd) {
+      f4 v = pv[rd];
+      if (phas) {
+        v = v * psc + psh;
+        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      v = v * xs;
+      if (!(geo[rd] & 0x80000000u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      if (geo[rd] & 0x00008000u) {
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = clamp_h(v[e]);
+          const _Float16 h = (_Float16)x;
+          hi[e] = h; lo[e] = (_Float16)(x - (float)h);
+        }
+        const int u = rd * 256 + tid;
+        _Float16* d = hsm + buf * kFBuf + (u >> 2) * kFPix + (u & 3) * 4;
+        *(h4*)d = hi;
+        *(h4*)(d + 16) = lo;
+      }
+    }
+  };
+
+  // ---- filter fragments: global -> registers, one tap pair ahead.  step t = chunk * 5 + ks
+  const _Float16* const wb = (const _Float16*)a.wu + (size_t)(n0 / 16) * 1024 + lane * 8;
+  const int nchunk = a.Ctot >> 4, nsteps = nchunk * kFKs;
+  constexpr int dbg = UWM_F16_ABL;
+  auto w_load = [&](int t, h8 (&whi)[4], h8 (&wlo)[4]) {
+    if ((dbg & 2) && t > 0) return;
+    const _Float16* p = wb + (size_t)t * nJ * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { whi[j] = *(const h8*)(p + j * 1024); wlo[j] = *(const h8*)(p + j * 1024 + 512); }
+  };
+  // ---- pixel fragments: lane (pixel column px16, group g) reads 8 channels of tap slot 2*ks + (g >> 1) at pixel row 4*wave + i
+  const int pbase = ((wave * 4) * kFP + px16) * kFPix + (g & 1) * 8;
+  const int ghi = g >> 1;
+  auto mma_step = [&](int ks, const _Float16* pc, const h8 (&whi)[4], const h8 (&wlo)[4]) {
+    const int slot0 = 2 * ks, slot1 = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;      // (slot 9: its weights are zero; read a valid address)
+    const int off0 = ((slot0 / 3) * kFP + slot0 % 3) * kFPix, off1 = ((slot1 / 3) * kFP + slot1 % 3) * kFPix;
+    const _Float16* pp = pc + pbase + (ghi ? off1 : off0);
+    h8 xh[4], xl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (dbg & 4) { xh[i] = whi[i]; xl[i] = wlo[i]; continue; }
+      xh[i] = *(const h8*)(pp + i * kFP * kFPix); xl[i] = *(const h8*)(pp + i * kFP * kFPix + 16);
+    }
+    if (dbg & 1) { acc[0][0][0] += (float)xh[0][0] + (float)xl[1][1] + (float)whi[2][2] + (float)wlo[3][3] + (float)xh[2][0] + (float)xh[3][0]; return; }
+    // the three products of a tile go to the SAME accumulator: issue them 16 tiles apart (a dependent MFMA waits ~2 issue
+    // slots for its predecessor's result), product type outermost
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+  };
+
+  h8 wA_hi[4], wA_lo[4], wB_hi[4], wB_lo[4];
+  w_load(0, wA_hi, wA_lo);
+  patch_load(0);
+  patch_store(0);
+  __syncthreads();
+
+  // two chunks (10 tap pairs) per iteration so that the two register sets of filter fragments alternate statically
+  for (int cc = 0; cc < nchunk; cc += 2) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int c = cc + hh, cur = hh, nxt = hh ^ 1;       // (nchunk is even: chunk c sits in buffer c & 1 = hh)
+      const int cn = c + 1 < nchunk ? c + 1 : c;           // last chunk: harmless re-fetch into the dead buffer
+      if (!(dbg & 8)) patch_load(cn);
+      const _Float16* pc = hsm + cur * kFBuf;
+#pragma unroll
+      for (int ks = 0; ks < kFKs; ++ks) {
+        const int t = c * kFKs + ks;
+        const int tnext = t + 1 < nsteps ? t + 1 : t;
+        if (((hh * kFKs + ks) & 1) == 0) { w_load(tnext, wB_hi, wB_lo); mma_step(ks, pc, wA_hi, wA_lo); }
+        else { w_load(tnext, wA_hi, wA_lo); mma_step(ks, pc, wB_hi, wB_lo); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(dbg & 8)) patch_store(nxt);
+      __syncthreads();
+    }
+  }
+  if (dbg & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[3][3][3] == 123.456f) a.out[0] = 1.f; return; }
+
+  // ---------------- epilogue: D[row = co 4g + e][col = pixel px16].  A lane holds 4 channels of one pixel per tile: stored
+  // straight from the accumulators a wave instruction writes sixteen 64-byte pieces (half cache lines: 49 of the 94 us of a
+  // layer1 launch).  So every wave passes its 64 px x 64 ch block through LDS (its own region, [pixel][64 + 4 pad] floats; the
+  // patch buffers are dead) and reads it back with lanes along the channels: 256 contiguous bytes per pixel, per-thread
+  // constant channel quad (row un-scale, bias, mask coefficients and the statistics stay in registers)
+  constexpr int kQLd = 68;
+  float* const R = (float*)hsm + wave * 64 * kQLd;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f4*)(R + (i * 16 + px16) * kQLd + j * 16 + g * 4) = acc[i][j];
+  __syncthreads();
+  const float* rinv = (const float*)a.wu + a.wu_rinv_off;
+  const float ixs = 1.f / xs;
+  const bool do_stats = a.ssum != nullptr;
+  const bool bnb = a.bnb_mean != nullptr;
+  const int cq = lane & 15, sub = lane >> 4;
+  const int co = n0 + cq * 4;
+  const bool cok = co < a.Cout;
+  f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
+  {
+    f4 rs = {0.f, 0.f, 0.f, 0.f}, bmu = rs, brs = rs, bia = rs, msc = {1.f, 1.f, 1.f, 1.f}, msh = rs;
+    if (cok) rs = *(const f4*)(rinv + co) * ixs;
+    if (bnb && cok) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
+    if (a.bias && cok) bia = *(const f4*)(a.bias + co);
+    if (a.mscale && cok) { msc = *(const f4*)(a.mscale + co); msh = *(const f4*)(a.mshift + co); }
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      const int p = r * 4 + sub;
+      const int ho = h0 + wave * 4 + (p >> 4), wo = w0 + (p & 15);
+      if (ho < a.Ho && wo < a.Wo && cok) {
+        const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
+        f4 v = *(const f4*)(R + p * kQLd + cq * 4) * rs + bia;
+        if (a.addend) v += *(const f4*)(a.addend + o);
+        f4 yr = {0.f, 0.f, 0.f, 0.f};
+        if (a.mask) {
+          f4 mk = *(const f4*)(a.mask + o);
+          yr = mk;
+          if (a.mscale) mk = mk * msc + msh;
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        *(f4*)(a.out + o) = v;
+        if (a.bnb_y) yr = *(const f4*)(a.bnb_y + o);
+        ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
+      }
+    }
+  }
+  if (do_stats) {
+    // the 4 pixel sub-rows of a wave (xor 16, 32) -> 4 waves through LDS -> fp64 atomics on one replica
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sv = ps_[e], qv = pq_[e];
+      sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
+      sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+      ps_[e] = sv; pq_[e] = qv;
+    }
+    __syncthreads();                             // every wave is done with its block
+    float* red = (float*)hsm;                    // [4 waves][64][2]
+    if (sub == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(wave * 64 + cq * 4 + e) * 2] = ps_[e]; red[(wave * 64 + cq * 4 + e) * 2 + 1] = pq_[e]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int c1 = n0 + tid;
+      if (c1 < a.Cout) {
+        double sv = 0.0, qv = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sv += (double)red[(w * 64 + tid) * 2]; qv += (double)red[(w * 64 + tid) * 2 + 1]; }
+        const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
+        atomicAdd(a.ssum + srep_off + c1, sv);
+        atomicAdd(a.ssq + srep_off + c1, qv);
+      }
+    }
+  }
+}
+
+// 3x3 / stride 1 / pad 1, 16-channel chunks in pairs on either side of a concat, whole 16x16 tiles not required (edges are
+// masked) but at least one; no fused concat split (ConvArgs::out_up stays on conv_wino_kernel)
+bool conv_f16x3_applicable(const ConvArgs& a) {
+  return a.wu != nullptr && a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && (a.rmul == 1 ? a.off == -1 : a.off == 1) &&
+         (a.Ctot & 31) == 0 && (a.C0 & 15) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && (a.Cout & 3) == 0 && a.Cout >= 16 &&
+         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= 8 && a.Wo >= 16 && !a.out_up && a.Hl < 32768 && a.Wl < 32768 &&
+         (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
+}
+
+hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st) {
+  if (!conv_f16x3_applicable(a)) return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.bnb_y ? a.bnb_y : a.mask))) return hipErrorInvalidValue;
+  const int tilesN = (a.Cout + 63) / 64;
+  const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
+  const size_t main_lds = (size_t)2 * kFBuf * sizeof(_Float16), q_lds = (size_t)4 * 64 * 68 * sizeof(float);
+  const size_t lds = main_lds > q_lds ? main_lds : q_lds;
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3_kernel, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(42, a.flops, a.bytes, conv_f16x3_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace uwm

@@ -786,7 +786,8 @@ const char* prof_class_name(int cls) {
       "conv_head_kernel",               "conv_wino_x3_kernel",            "wgrad_c16_kernel",
       "wgrad_head_kernel",              "conv_up2_kernel",                "conv_up2_dgrad_kernel",
       "wgrad_up2_kernel",               "conv_gemm_kernel<128>",          "conv_gemm_kernel<64>",
-      "wgrad_gemm_kernel<128>",         "wgrad_gemm_kernel<64>",          "wgrad_stem_kernel"};
+      "wgrad_gemm_kernel<128>",         "wgrad_gemm_kernel<64>",          "wgrad_stem_kernel",
+      "conv_f16x3_kernel"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

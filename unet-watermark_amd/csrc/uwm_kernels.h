@@ -88,7 +88,9 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   const float* wu;           // Winograd-transformed weights (conv_wino.hip layout) or nullptr
   int wu_ncb;                // 16-row blocks per xi in wu
   int wino;                  // Winograd mode of this launch: 0 = process default (uwm_set_winograd), else mode + 1 (per-handle: uwm_set_winograd_mode)
-  int prec;                  // 1: wu is a bf16x3 bank (conv_wino_x3.hip layout) and the launch goes to the split-bf16 kernel; 0: fp32
+  int prec;                  // 1: wu is a bf16x3 bank (conv_wino_x3.hip layout) and the launch goes to the split-bf16 kernel; 2: wu is an fp16x3 bank (conv_f16x3.hip: direct form on v_mfma_f32_16x16x32_f16, fp32-class accuracy); 0: fp32
+  int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
+  const float* xscale;       // prec 2: device scalar, power-of-two scale applied to the input while staging (a dgrad's dY; nullptr = 1) and undone in the epilogue
 };
 
 // Deferred partial-sum reduces.  A split weight-gradient launch leaves `nsplit` dW-shaped partial images in scratch; adding them
@@ -124,7 +126,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 42 };   // 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 43 };   // 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -195,6 +197,13 @@ struct WinoJobs { WinoJob j[40]; int n; };
 hipError_t launch_wino_weights_multi(const WinoJobs& jobs, hipStream_t st);   // every layer's transform in one launch
 // bf16x3 precision mode (conv_wino_x3.hip): split-bf16 filter banks (same size as the fp32 ones) and the conv kernel; force_cfg 400
 hipError_t launch_wino_weights_x3_multi(const WinoJobs& jobs, hipStream_t st);
+// fp16x3 direct convolution (conv_f16x3.hip): split-fp16 filter banks and the conv kernel; force_cfg 600
+int f16x3_nj(int rows);
+size_t f16x3_bank_floats(int rows, int chans);             // bank size in floats, 1 / row-scale array included
+size_t f16x3_rinv_off(int rows, int chans);                 // float offset of that array in the bank
+hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st);
+bool conv_f16x3_applicable(const ConvArgs& a);
+hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st);
 bool conv_wino_x3_applicable(const ConvArgs& a);
 hipError_t launch_conv_wino_x3(const ConvArgs& a, hipStream_t st);
 // process default (UWM_WINOGRAD / uwm_set_winograd): used by the single-operator entry points and by handles created later

@@ -54,6 +54,9 @@ struct ConvL {
   // bf16x3 precision mode: whole 16-channel chunks on either side of the concat (conv_wino_x3.hip)
   bool x3() const { return wino() && (CinP & 15) == 0 && (c0 & 15) == 0; }
   bool x3_d() const { return wino_d() && (CoutP & 15) == 0; }
+  // fp16x3 direct form (conv_f16x3.hip): chunk pairs of 16 channels on either side of the concat
+  bool f3() const { return wino() && (CinP & 31) == 0 && (c0 & 15) == 0 && Cout >= 16; }
+  bool f3_d() const { return wino_d() && (CoutP & 31) == 0 && CinP >= 16; }
 };
 // encoder residual block.  BasicBlock: c1 3x3(stride) -> c2 3x3, c3 = -1.  Bottleneck: c1 1x1 -> c2 3x3(stride) -> c3 1x1(x4).
 struct BlockL { int c1, c2, cd, c3 = -1, stride = 1, Cin = 0, Cout = 0; int last() const { return c3 >= 0 ? c3 : c2; } };
@@ -315,8 +318,9 @@ static int build_model(uwm_model* m) {
   f = (size_t)rup((long long)f, 64);
   for (auto& c : m->convs) if (c.dgrad) { c.wd_off = f; f += (size_t)c.CinP * c.KpadD; f = (size_t)rup((long long)f, 64); }
   for (auto& c : m->convs) {
-    if (c.wino()) { c.wu_off = f; f += wino_weights_floats(c.Cout, c.CinP); f = (size_t)rup((long long)f, 64); }
-    if (c.wino_d()) { c.wud_off = f; f += wino_weights_floats(c.CinP, c.CoutP); f = (size_t)rup((long long)f, 64); }
+    // (one slot per direction holds whichever bank the precision mode asks for: fp32 Winograd, bf16x3 Winograd or fp16x3 direct)
+    if (c.wino()) { c.wu_off = f; f += std::max(wino_weights_floats(c.Cout, c.CinP), c.f3() ? f16x3_bank_floats(c.Cout, c.CinP) : 0); f = (size_t)rup((long long)f, 64); }
+    if (c.wino_d()) { c.wud_off = f; f += std::max(wino_weights_floats(c.CinP, c.CoutP), c.f3_d() ? f16x3_bank_floats(c.CinP, c.CoutP) : 0); f = (size_t)rup((long long)f, 64); }
   }
   m->fixed_floats = f;
 
@@ -482,6 +486,14 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
   m->plan = p;
 }
 
+// a conv takes the fp16x3 direct kernel (forward) when its shape is eligible AND the launch fills the chip: 16x16-pixel x 64-channel
+// workgroups, at least one per CU (layer4-sized launches at small batch / resolution stay on the Winograd kernels)
+static bool f3_fwd_on(const uwm_model* m, size_t ci) {
+  const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
+  if (p.prec < UWM_PREC_F16X3 || !cv.f3() || !p.wino_ok(ci)) return false;
+  const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
+  return wgs >= device_cu_count();
+}
 // ------------------------------------------------------------------------------ launch helpers
 struct Ctx {
   uwm_model* m; float* ws; hipStream_t st; int N;
@@ -524,6 +536,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
       if (a.C0 != cv.c0 && a.C0 != a.Ctot) return hipErrorInvalidValue;       // the bank was split for this concat boundary
       a.prec = 1;
     }
+    if (f3_fwd_on(c.m, (size_t)ci)) { a.prec = 2; a.wu_ncb = f16x3_nj(cv.Cout); a.wu_rinv_off = (int)f16x3_rinv_off(cv.Cout, cv.CinP); }
   }
   a.wino = c.m->plan.wino_mode + 1;
   return launch_conv(a, c.st, cfg);
@@ -657,20 +670,32 @@ static hipError_t run_bn_bwd_act(const Ctx& c, int ci, const float* g, float* dy
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("launch failed: %s at %s:%d (%s)",  \
        hipGetErrorString(e_), __FILE__, __LINE__, #expr); } while (0)
 
+// fp16x3 dgrads cover the plain epilogue only: a decoder conv1 (its dgrad splits the concat gradient in the epilogue: ConvArgs::out_up)
+// keeps the Winograd kernel
+static bool f3d_plain(const uwm_model* m, int ci) {
+  for (auto& d : m->dec) if (d.c1 == ci) return false;
+  for (auto& nd : m->nodes) if (nd.c1 == ci) return false;
+  return true;
+}
 // Winograd filter transforms of every eligible layer (forward banks, or dgrad banks straight from the forward
 // weights), at most 40 layers per launch
 static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
   if (c.m->plan.wino_mode == 0) return hipSuccess;
   const uwm_model* m = c.m;
-  // two passes: fp32 banks, then (bf16x3 precision mode) the split-bf16 banks of the layers that run on conv_wino_x3
-  for (int x3 = 0; x3 <= (m->plan.prec != UWM_PREC_F32 ? 1 : 0); ++x3) {
+  // three passes: fp32 banks, then (bf16x3 modes) the split-bf16 banks of the layers that run on conv_wino_x3, then (fp16x3
+  // modes) the split-fp16 banks of the layers that run on conv_f16x3
+  const int prec = m->plan.prec;
+  const bool bf = prec == UWM_PREC_BF16X3 || prec == UWM_PREC_BF16X3_ALL;
+  for (int x3 = 0; x3 <= 2; ++x3) {
     WinoJobs jobs; jobs.n = 0;
-    auto flush = [&]() { hipError_t e = x3 ? launch_wino_weights_x3_multi(jobs, st) : launch_wino_weights_multi(jobs, st); jobs.n = 0; return e; };
+    auto flush = [&]() { hipError_t e = x3 == 2 ? launch_f16x3_weights_multi(jobs, st) : (x3 ? launch_wino_weights_x3_multi(jobs, st) : launch_wino_weights_multi(jobs, st)); jobs.n = 0; return e; };
     for (size_t ci = 0; ci < m->convs.size(); ++ci) {
       const ConvL& cv = m->convs[ci];
       if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off)) continue;
-      const bool is_x3 = dgrad ? (m->plan.prec != UWM_PREC_F32 && cv.x3_d()) : (m->plan.prec == UWM_PREC_BF16X3_ALL && cv.x3());
-      if (is_x3 != (x3 == 1)) continue;
+      int kind = 0;
+      if (dgrad) { if (bf && cv.x3_d()) kind = 1; if (prec == UWM_PREC_F16X3_ALL && cv.f3_d() && f3d_plain(m, (int)ci)) kind = 2; }
+      else { if (prec == UWM_PREC_BF16X3_ALL && cv.x3()) kind = 1; if (f3_fwd_on(m, ci)) kind = 2; }
+      if (kind != x3) continue;
       WinoJob& j = jobs.j[jobs.n++];
       j.w = m->params + cv.w_off; j.Kpad = cv.Kpad; j.pad_ = 0;
       if (dgrad) { j.ut = c.F(cv.wud_off); j.rows = cv.CinP; j.chans = cv.CoutP; j.mode = 2; j.src_rows = cv.Cout; }
@@ -707,7 +732,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     }
     LCHK(wino_jobs(c, true, m->side));
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
-    m->packed_in_fwd = true; m->pack_mode = p.wino_mode * 4 + p.prec;
+    m->packed_in_fwd = true; m->pack_mode = p.wino_mode * 8 + p.prec;
   }
   LCHK(wino_jobs(c, false, st));
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
@@ -884,7 +909,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
     HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
     if (p.se_gs_floats) HIPCHK(hipMemsetAsync(c.F(p.se_gs_all), 0, p.se_gs_floats * sizeof(float), st));
-    if (m->packed_in_fwd && m->pack_mode == p.wino_mode * 4 + p.prec) {      // (a mode switch between forward and backward: redo them)
+    if (m->packed_in_fwd && m->pack_mode == p.wino_mode * 8 + p.prec) {      // (a mode switch between forward and backward: redo them)
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
       m->packed_in_fwd = false;           // joined
     } else {
@@ -1481,6 +1506,23 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st, bool x3 = fa
   a.wu = buf; a.wu_ncb = wino_ncb(a.wrows);
   return 0;
 }
+// fp16x3 bank for the op-level entry point (tests / timing): cfg 600
+static int op_f16x3_prepare(ConvArgs& a, hipStream_t st) {
+  static float* buf = nullptr; static size_t cap = 0;
+  if (a.Ctot & 31) return fail("uwm_op_conv: cfg 600 (fp16x3) needs channels %% 32 == 0");
+  const size_t need = f16x3_bank_floats(a.wrows, a.Ctot);
+  if (need > cap) {
+    HIPCHK(hipDeviceSynchronize());
+    if (buf) HIPCHK(hipFree(buf));
+    HIPCHK(hipMalloc((void**)&buf, need * sizeof(float))); cap = need;
+  }
+  WinoJobs jobs; jobs.n = 1;
+  WinoJob& j = jobs.j[0];
+  j.w = a.w; j.ut = buf; j.rows = a.wrows; j.chans = a.Ctot; j.Kpad = a.Kpad; j.mode = 0; j.src_rows = a.wrows; j.pad_ = 0;
+  LCHK(launch_f16x3_weights_multi(jobs, st));
+  a.wu = buf; a.wu_ncb = f16x3_nj(a.wrows); a.wu_rinv_off = (int)f16x3_rinv_off(a.wrows, a.Ctot); a.prec = 2;
+  return 0;
+}
 static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad) {
   return kh == 3 && kw == 3 && stride == 1 && pad == 1 && (a.Ctot & 7) == 0 && (a.C0 & 7) == 0 && a.Ho >= 8 && a.Wo >= 16;
 }
@@ -1520,8 +1562,8 @@ int uwm_set_winograd_mode(uwm_handle h, int mode) {
 int uwm_get_winograd_mode(uwm_handle h) { return h ? h->wino_mode : -1; }
 int uwm_set_precision(uwm_handle h, int mode) {
   if (!h) return fail("uwm_set_precision: null handle");
-  if (mode != UWM_PREC_F32 && mode != UWM_PREC_BF16X3 && mode != UWM_PREC_BF16X3_ALL)
-    return fail("uwm_set_precision: mode must be UWM_PREC_F32 (0), UWM_PREC_BF16X3 (1) or UWM_PREC_BF16X3_ALL (2), got %d", mode);
+  if (mode < UWM_PREC_F32 || mode > UWM_PREC_F16X3_ALL)
+    return fail("uwm_set_precision: mode must be UWM_PREC_F32 (0), UWM_PREC_BF16X3 (1), UWM_PREC_BF16X3_ALL (2), UWM_PREC_F16X3 (3) or UWM_PREC_F16X3_ALL (4), got %d", mode);
   h->prec = mode; h->plan.prec = mode;          // the workspace layout does not depend on the mode (the banks have one size)
   return 0;
 }
@@ -1574,7 +1616,10 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
-  if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
+  if (cfg == 600) {
+    if (!op_wino_shape(a, kh, kw, stride, pad)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs 3x3 s1 p1, Ho >= 8, Wo >= 16");
+    if (op_f16x3_prepare(a, (hipStream_t)stream)) return 1;
+  } else if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
     if (op_wino_prepare(a, 0, (hipStream_t)stream, cfg == 400)) return 1;
   } else if (cfg >= 300 && cfg < 500) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
   LCHK(launch_conv(a, (hipStream_t)stream, cfg));
