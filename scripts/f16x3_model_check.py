@@ -10,7 +10,7 @@ x, t = O.synthetic_batch(2, 256, 256, seed=42)
 ref.train()
 o_ref = ref(x); l_ref = O.DiceLoss(smooth=1e-5)(o_ref, t.unsqueeze(1)); l_ref.backward()
 gref = dict(ref.named_parameters())
-for mode in ("f32", "f16x3"):
+for mode in ("f32", "f16x3", "f16x3_all"):
     m = U.Unet("resnet34").to(dev); m.load_state_dict(ref.state_dict()); m.train(); m.set_precision(mode)
     o = m(x.to(dev)); l = U.DiceLoss(mode="binary", smooth=1e-5)(o, t.unsqueeze(1).to(dev)); l.backward()
     err = float((o.detach().cpu() - o_ref.detach()).abs().max())
@@ -21,7 +21,7 @@ for mode in ("f32", "f16x3"):
     print(mode, "logit err vs oracle %.3e" % err, "loss diff %.2e" % abs(float(l) - float(l_ref)), "min grad cos %.6f" % cmin)
 torch.manual_seed(0)
 xb = torch.randn(16, 3, 512, 512, device=dev); tb = (torch.rand(16, 512, 512, device=dev) > 0.8).to(torch.uint8)
-for mode in ("f32", "f16x3"):
+for mode in ("f32", "f16x3", "f16x3_all"):
     m = U.Unet("resnet34").to(dev); m.set_precision(mode)
     tr = Trainer(m, lr=1e-4)
     for _ in range(10): tr.step(xb, tb)

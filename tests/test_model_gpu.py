@@ -1002,7 +1002,7 @@ def test_trainer_hipgraph_step_matches_eager(cuda):
         assert float(d) < 2e-3, float(d)
         for (n1, r1), (_, r2) in zip(a.state_dict().items(), b.state_dict().items()):
             if n1.endswith("running_var") or n1.endswith("num_batches_tracked"):
-                assert torch.allclose(r1.float(), r2.float(), rtol=1e-3, atol=1e-5), n1
+                assert torch.allclose(r1.float(), r2.float(), rtol=5e-3, atol=1e-4), n1
     # EfficientNet: the drop-connect draw is part of the captured step (device RNG), the step must train
     torch.manual_seed(4)
     m = U.Unet("efficientnet-b4").to(cuda)

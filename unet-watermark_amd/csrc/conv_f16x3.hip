@@ -162,7 +162,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
     geo[rd] = ((unsigned)hc << 16) | (unsigned)wc | (ok ? 0x80000000u : 0u) | (act ? 0x00008000u : 0u);
   }
-  const float xs = a.xscale ? *a.xscale : 1.f;          // dgrad: power-of-two scale of dY (1 for activations)
+  // dgrad: dY is tiny (1e-3 ... 1e-9): it is staged times the power of two that puts max|dY| into [2^13, 2^14) (exact; undone in
+  // the epilogue).  max|dY| = the maximum of the 32 slots bn_bwd_apply filled; activations are staged as they are
+  float xs = 1.f;
+  if (a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
   f4 pv[kFRounds], psc, psh; int prelu = 0; bool phas = false;
   auto patch_load = [&](int cc) {
     const int c = cc * 16;

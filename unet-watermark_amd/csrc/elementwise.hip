@@ -304,8 +304,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const double* __restrict__ dgamma, const double* __restrict__ dbeta, float* __restrict__ dy,
                                     float* gamma_grad, float* beta_grad, size_t n4, int C, float invM,
-                                    const double* __restrict__ rep, int nrep, int rep_stride) {
+                                    const double* __restrict__ rep, int nrep, int rep_stride, float* xmax) {
   __shared__ double part[256 * 8];
+  __shared__ float wmax[4];
+  float amax = 0.f;                                  // max |dy| of this thread's outputs (xmax != nullptr)
   // dy = gm*rs*(g - db - (y-mu)*rs*dg) = A*g + B*y + K per channel; the grid stride is a multiple of C/4, so a thread
   // keeps ONE channel quad: coefficients computed once, four 16-byte loads of each tensor in flight per iteration
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -353,13 +355,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) { gamma_grad[c + e] = (float)sdg[e]; beta_grad[c + e] = (float)sdb[e]; }
   }
-  if (i >= n4) return;
+  if (i >= n4 && !xmax) return;
   f4 dg, db;
   dg.x = (float)sdg[0] * invM; dg.y = (float)sdg[1] * invM; dg.z = (float)sdg[2] * invM; dg.w = (float)sdg[3] * invM;
   db.x = (float)sdb[0] * invM; db.y = (float)sdb[1] * invM; db.z = (float)sdb[2] * invM; db.w = (float)sdb[3] * invM;
   const f4 A = gm * rs, B = -(gm * rs * rs * dg), K = -(A * db) - B * mu;
+  auto amax4 = [&](const f4& v) { amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); };
   while (full) {
     const f4 o0 = A * g0 + B * y0 + K, o1 = A * g1 + B * y1 + K, o2 = A * g2 + B * y2 + K, o3 = A * g3 + B * y3 + K;
+    if (xmax) { amax4(o0); amax4(o1); amax4(o2); amax4(o3); }
     const size_t io = i;
     i += 4 * stride;
     full = i + 3 * stride < n4;
@@ -372,11 +376,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     *(f4*)(dy + (io + 2 * stride) * 4) = o2;
     *(f4*)(dy + (io + 3 * stride) * 4) = o3;
   }
-  for (; i < n4; i += stride) *(f4*)(dy + i * 4) = A * *(const f4*)(g + i * 4) + B * *(const f4*)(y + i * 4) + K;
+  for (; i < n4; i += stride) {
+    const f4 o = A * *(const f4*)(g + i * 4) + B * *(const f4*)(y + i * 4) + K;
+    if (xmax) amax4(o);
+    *(f4*)(dy + i * 4) = o;
+  }
+  if (xmax) {                                        // wave max -> workgroup max -> one atomic on one of 32 slots (non-negative floats order as integers)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      if (mx > 0.f) atomicMax((unsigned*)xmax + (blockIdx.x & 31), __float_as_uint(mx));
+    }
+  }
 }
 hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd, const float* gamma,
                                const double* dgamma, const double* dbeta, float* dy, float* gamma_grad, float* beta_grad,
-                               size_t npix, int C, hipStream_t st, const double* rep, int nrep, int rep_stride, hipEvent_t done) {
+                               size_t npix, int C, hipStream_t st, const double* rep, int nrep, int rep_stride, hipEvent_t done, float* xmax) {
   const size_t n4 = npix * C / 4;
   // grid stride (blocks x 256) must be a multiple of C/4 so that every thread stays on one channel quad
   unsigned nb = nblocks(n4, 256 * 4);
@@ -390,10 +408,10 @@ hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean
   // ~8 us of queue-processing latency on the dependent chain, 40 times per step)
   if (done)
     hipExtLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, st, nullptr, done, 0, g, y, mean, rstd, gamma, dgamma,
-                          dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix), rep, rep ? (nrep < 1 ? 1 : nrep) : 0, rep_stride);
+                          dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix), rep, rep ? (nrep < 1 ? 1 : nrep) : 0, rep_stride, xmax);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, st, g, y, mean, rstd, gamma, dgamma,
-                       dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix), rep, rep ? (nrep < 1 ? 1 : nrep) : 0, rep_stride);
+                       dbeta, dy, gamma_grad, beta_grad, n4, C, (float)(1.0 / (double)npix), rep, rep ? (nrep < 1 ? 1 : nrep) : 0, rep_stride, xmax);
   return hipGetLastError();
 }
 

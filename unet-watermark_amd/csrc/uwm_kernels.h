@@ -90,7 +90,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int wino;                  // Winograd mode of this launch: 0 = process default (uwm_set_winograd), else mode + 1 (per-handle: uwm_set_winograd_mode)
   int prec;                  // 1: wu is a bf16x3 bank (conv_wino_x3.hip layout) and the launch goes to the split-bf16 kernel; 2: wu is an fp16x3 bank (conv_f16x3.hip: direct form on v_mfma_f32_16x16x32_f16, fp32-class accuracy); 0: fp32
   int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
-  const float* xscale;       // prec 2: device scalar, power-of-two scale applied to the input while staging (a dgrad's dY; nullptr = 1) and undone in the epilogue
+  const float* xmax;         // prec 2: 32 device floats whose maximum is max|input| (a dgrad's dY, written by bn_bwd_apply), or nullptr: the input is staged times the power of two that puts that maximum in [2^13, 2^14), undone in the epilogue
 };
 
 // Deferred partial-sum reduces.  A split weight-gradient launch leaves `nsplit` dW-shaped partial images in scratch; adding them
@@ -234,7 +234,8 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
 hipError_t launch_bn_bwd_apply(const float* g, const float* y, const float* mean, const float* rstd,
                                const float* gamma, const double* dgamma, const double* dbeta, float* dy,
                                float* gamma_grad, float* beta_grad, size_t npix, int C, hipStream_t st,
-                               const double* rep = nullptr, int nrep = 0, int rep_stride = 0, hipEvent_t done = nullptr);   // rep: fold the nrep replicas {dbeta part[C], dgamma part[C]} of a fused dgrad epilogue in the prologue (dgamma / dbeta unused)
+                               const double* rep = nullptr, int nrep = 0, int rep_stride = 0, hipEvent_t done = nullptr,
+                               float* xmax = nullptr);   // xmax: 32 zero-initialised floats; slot (workgroup & 31) receives max|dy| of the workgroup (ConvArgs::xmax of the fp16x3 dgrad that reads dy)   // rep: fold the nrep replicas {dbeta part[C], dgamma part[C]} of a fused dgrad epilogue in the prologue (dgamma / dbeta unused)
 // dcat [N][H][W][C0+C1] -> gprev [N][H/2][W/2][C0] = mask(sum 2x2), gskip [N][H][W][C1] (copy)
 hipError_t launch_upsplit(const float* dcat, int N, int H, int W, int C0, int C1, float* gprev,
                           const float* pmask, const float* pscale, const float* pshift, float* gskip,

@@ -35,9 +35,10 @@ struct BNL {
   std::string name; int C; int stage;
   long long g_off, b_off;          // param arena
   long long rm_off, rv_off;        // buffer arena
-  size_t d_off;                    // workspace doubles: dgamma[C], dbeta[C], then nrep copies of {sum[C], sq[C]}
+  size_t d_off;                    // workspace doubles: dgamma[C], dbeta[C], then nrep copies of {sum[C], sq[C]}, then 32 floats of max|dy|
   int nrep;                        // statistics copies (power of 2): spreads the conv epilogues' fp64 atomics
-  size_t dcount() const { return 2 * (size_t)C + (size_t)nrep * 2 * C; }
+  size_t dcount() const { return 2 * (size_t)C + (size_t)nrep * 2 * C + 16; }     // (+ 16 doubles = the 32 float slots of max|dy|: fp16x3 dgrad scaling, zeroed with the sums)
+  size_t xmax_off() const { return d_off + dcount() - 16; }                         // in doubles
   size_t f_off;                    // workspace floats: mean, rstd, scale, shift (4*C)
   float eps = 0.f, mom = 0.f;      // 0 = the descriptor's bn_eps / bn_momentum (EfficientNet encoder layers carry their own)
 };
@@ -494,6 +495,19 @@ static bool f3_fwd_on(const uwm_model* m, size_t ci) {
   const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
   return wgs >= device_cu_count();
 }
+// fp16x3 dgrads cover the plain epilogue only: a decoder conv1 (its dgrad splits the concat gradient in the epilogue: ConvArgs::out_up)
+// keeps the Winograd kernel
+static bool f3d_plain(const uwm_model* m, int ci) {
+  for (auto& d : m->dec) if (d.c1 == ci) return false;
+  for (auto& nd : m->nodes) if (nd.c1 == ci) return false;
+  return true;
+}
+static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
+  const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
+  if (p.prec != UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
+  const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
+  return wgs >= device_cu_count();
+}
 // ------------------------------------------------------------------------------ launch helpers
 struct Ctx {
   uwm_model* m; float* ws; hipStream_t st; int N;
@@ -563,7 +577,15 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
   a.flops = 2.0 * (double)c.N * Ho * Wo * cv.Cout * cv.Cin * cv.k * cv.k;   // same MACs as the forward conv
   a.bytes = 4.0 * ((double)c.N * Ho * Wo * cv.CoutP + (double)cv.CinP * cv.KpadD +
                    (double)a.M * cv.CinP * (1.0 + (addend ? 1.0 : 0.0) + (mask ? 1.0 : 0.0)));
-  if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) { a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP); if (c.m->plan.prec != UWM_PREC_F32 && cv.x3_d()) a.prec = 1; }
+  if (cv.wud_off && c.m->plan.wino_ok((size_t)ci)) {
+    a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP);
+    const int pm = c.m->plan.prec;
+    if ((pm == UWM_PREC_BF16X3 || pm == UWM_PREC_BF16X3_ALL) && cv.x3_d()) a.prec = 1;
+    if (f3_dgrad_on(c.m, (size_t)ci) && !us) {        // fp16x3 direct form: dY scaled by the power of two bn_bwd_apply's max|dy| calls for
+      a.prec = 2; a.wu_ncb = f16x3_nj(cv.CinP); a.wu_rinv_off = (int)f16x3_rinv_off(cv.CinP, cv.CoutP);
+      a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off());
+    }
+  }
   a.wino = c.m->plan.wino_mode + 1;
   if (us) { a.out_up = us->gprev; a.up_c0 = us->C0; a.up_mask = us->pmask; a.up_mscale = us->pscale; a.up_mshift = us->pshift; a.up_accum = us->accumulate; }
   if (fused) *fused = false;
@@ -645,14 +667,15 @@ static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, si
     if (cs == hipStreamCaptureStatusNone) done = m->ev_disp;          // (a capturing stream takes the plain record / wait pair: graph edges)
   }
   hipError_t e = hipSuccess;
+  float* xmax = f3_dgrad_on(m, (size_t)ci) ? (float*)c.D(b.xmax_off()) : nullptr;      // the fp16x3 dgrad of this conv scales dy by its maximum
   if (sums_fused)
     e = launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, nullptr, nullptr, dy, m->grads + b.g_off, m->grads + b.b_off,
-                            npix, b.C, c.st, c.D(b.d_off) + 2 * b.C, b.nrep, 2 * b.C, done);
+                            npix, b.C, c.st, c.D(b.d_off) + 2 * b.C, b.nrep, 2 * b.C, done, xmax);
   else {
     e = launch_bn_bwd_reduce(g, y, f, f + b.C, dg, db, npix, b.C, c.st);
     if (e != hipSuccess) return e;
     e = launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, dg, db, dy, m->grads + b.g_off, m->grads + b.b_off,
-                            npix, b.C, c.st, nullptr, 0, 0, done);
+                            npix, b.C, c.st, nullptr, 0, 0, done, xmax);
   }
   if (e == hipSuccess && done) m->disp_cov.push_back(dy);
   return e;
@@ -670,13 +693,6 @@ static hipError_t run_bn_bwd_act(const Ctx& c, int ci, const float* g, float* dy
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("launch failed: %s at %s:%d (%s)",  \
        hipGetErrorString(e_), __FILE__, __LINE__, #expr); } while (0)
 
-// fp16x3 dgrads cover the plain epilogue only: a decoder conv1 (its dgrad splits the concat gradient in the epilogue: ConvArgs::out_up)
-// keeps the Winograd kernel
-static bool f3d_plain(const uwm_model* m, int ci) {
-  for (auto& d : m->dec) if (d.c1 == ci) return false;
-  for (auto& nd : m->nodes) if (nd.c1 == ci) return false;
-  return true;
-}
 // Winograd filter transforms of every eligible layer (forward banks, or dgrad banks straight from the forward
 // weights), at most 40 layers per launch
 static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
@@ -693,7 +709,7 @@ static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
       const ConvL& cv = m->convs[ci];
       if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off)) continue;
       int kind = 0;
-      if (dgrad) { if (bf && cv.x3_d()) kind = 1; if (prec == UWM_PREC_F16X3_ALL && cv.f3_d() && f3d_plain(m, (int)ci)) kind = 2; }
+      if (dgrad) { if (bf && cv.x3_d()) kind = 1; if (f3_dgrad_on(m, ci)) kind = 2; }
       else { if (prec == UWM_PREC_BF16X3_ALL && cv.x3()) kind = 1; if (f3_fwd_on(m, ci)) kind = 2; }
       if (kind != x3) continue;
       WinoJob& j = jobs.j[jobs.n++];
@@ -1182,6 +1198,11 @@ int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
   if (build_model(m)) { delete m; return 1; }
   const char* e = getenv("UWM_SIDE_STREAM");
   m->use_side = e ? atoi(e) : 1;
+  if (const char* pe = getenv("UWM_PRECISION")) {      // process default of the precision mode (like UWM_WINOGRAD): f32 | bf16x3 | bf16x3_all | f16x3 | f16x3_all or 0..4
+    static const char* names[5] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all"};
+    for (int i = 0; i < 5; ++i) if (!strcmp(pe, names[i]) || (pe[0] == '0' + i && !pe[1])) m->prec = i;
+    m->plan.prec = m->prec;
+  }
   m->wino_mode = winograd_mode();       // process default (UWM_WINOGRAD / uwm_set_winograd) at creation; then per handle
   m->plan.wino_mode = m->wino_mode;
   *out = m; return 0;

@@ -147,7 +147,7 @@ class Unet(nn.Module):
         self._n_mb = lib.uwm_num_mbconv_blocks(h)
         self._mb_drop = [float(lib.uwm_mbconv_drop_rate(h, i)) for i in range(self._n_mb)]
         self.drop_connect = self._n_mb > 0
-        self.precision = "f32"
+        self.precision = {v: k for k, v in L.PREC.items()}[lib.uwm_get_precision(h)]       # the process default (UWM_PRECISION) or "f32"
         self._fused_opt_ref = None        # weakref to the fused flat optimizer that consumes the gradient arena itself (train.py)
         self._keep_override = None        # tests: {0,1} keep masks [n_blocks, N] instead of a random draw
         self._rowscale = None
