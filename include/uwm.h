@@ -266,7 +266,8 @@ int  uwm_op_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, const float*
                   int stride, int pad, int H, int W, const float* addend, const float* mask, const float* mscale,
                   const float* mshift, float* dx, uwm_stream stream);
 /* force_igemm: 0 = the library's routing (Winograd-domain / sub-pixel / 16-channel / stem / 1x1-GEMM kernels where they apply);
- * 1 = flattened implicit GEMM only; 2 = no Winograd; 4 = wgrad_gemm.hip wherever applicable (tests / timing) */
+ * 1 = flattened implicit GEMM only; 2 = no Winograd; 4 = wgrad_gemm.hip wherever applicable; 6 = the fp16x3 direct weight
+ * gradient (wgrad_f16x3.hip: 3x3 stride 1, channels % 32 == 0, Wo % 32 == 0, Ho % 4 == 0) (tests / timing) */
 int  uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, int Ho, int Wo, int Cout, int wrows,
                   int Kpad, int kh, int kw, int stride, int pad, float* dw, int force_igemm, uwm_stream stream);
 int  uwm_op_pack_dgrad(const float* w, int Cout, int Kpad, int ntaps, int Cin, float* wd, int KpadD, int CoutP,

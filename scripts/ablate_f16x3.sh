@@ -7,8 +7,12 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p unet-watermark_amd/abl
 python -c "import sys; sys.path.insert(0,'.'); import __graft_entry__ as g; g.build()"
+# `scripts/ablate_f16x3.sh wgrad <bits...>`: the same for wgrad_f16x3.hip (UWM_WG16_ABL: 1 no MFMA, 2 no X fragment reads, 4 no loader
+# work after the first stage) -> libuwm_wg16_<bits>.so, for scripts/time_wgrad_f16x3.py
+src=conv_f16x3; def=UWM_F16_ABL; tag=f16
+if [ "$1" = wgrad ]; then src=wgrad_f16x3; def=UWM_WG16_ABL; tag=wg16; shift; fi
 for b in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DUWM_F16_ABL=$b -c unet-watermark_amd/csrc/conv_f16x3.hip -o unet-watermark_amd/abl/conv_f16x3_$b.o
-  objs=$(ls unet-watermark_amd/build/*.o | grep -v conv_f16x3.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o unet-watermark_amd/abl/libuwm_f16_$b.so $objs unet-watermark_amd/abl/conv_f16x3_$b.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -D$def=$b -c unet-watermark_amd/csrc/$src.hip -o unet-watermark_amd/abl/${src}_$b.o
+  objs=$(ls unet-watermark_amd/build/*.o | grep -v /$src.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o unet-watermark_amd/abl/libuwm_${tag}_$b.so $objs unet-watermark_amd/abl/${src}_$b.o
 done

@@ -810,3 +810,65 @@ def test_conv_f16x3_upsample_concat(cuda):
     L.check(L.lib().uwm_op_conv(C.byref(s0), C.byref(s1), P(wp), cout, kpad, 3, 3, 1, 1, n, cout, None, P(y), None, 600, stream()))
     torch.cuda.synchronize()
     assert (nchw(y.cpu()) - ref).abs().max() < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", [
+    (2, 64, 64, 16, 32, 1.0),        # layer1-like: one output-channel tile, two input-channel tiles
+    (1, 32, 128, 8, 64, 1e-6),       # two output-channel tiles; dY as tiny as a real Dice gradient (scaled through xmax)
+    (3, 96, 80, 12, 32, 1e-3),       # Cout 80 over-hangs the 64-channel tile; odd stage counts per split
+])
+def test_wgrad_f16x3_direct(cuda, case):
+    """wgrad_f16x3.hip (force 6): direct 3x3 weight gradient on v_mfma_f32_16x16x32_f16, pixels as the MFMA K dimension
+    (transposing LDS reads), fp16x3 split products with dY scaled by the power of two of its maximum: the fp32 bar of the
+    other weight-gradient kernels (3e-5 of the gradient's range), with a lazy BatchNorm + ReLU input."""
+    L = lib()
+    n, cin, cout, h, w, dmag = case
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, cin, h, w, generator=g)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    xin = torch.relu(x * sc[:, None, None] + sh[:, None, None])
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(xin.double(), wt.double(), None, 1, 1)
+    dy = torch.randn(y.shape, generator=g) * dmag
+    dy[:, :, :, : w // 2] *= 1e-3                         # a wide dynamic range inside the tensor
+    ref = torch.autograd.grad(y, wt, dy.double())[0]
+    xd, dyd = nhwc(x).to(cuda), nhwc(dy).to(cuda)
+    kpad = rup(9 * cin, 32)
+    dw = torch.zeros(cout, kpad, device=cuda)
+    scd, shd = sc.to(cuda), sh.to(cuda)                    # (src() keeps nothing alive)
+    s0 = src(xd, scd, shd, relu=1)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h, w, cout, cout, kpad, 3, 3, 1, 1, P(dw), 6, stream()))
+    torch.cuda.synchronize()
+    got = unpack_w(dw.cpu(), cout, cin, 3, 3).double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < 3e-5 * float(ref.abs().max()), float((got - ref).abs().max() / ref.abs().max())
+    # twice the same launch: bit-identical (partial images + ordered reduce, no atomics)
+    dw2 = torch.zeros(cout, kpad, device=cuda)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h, w, cout, cout, kpad, 3, 3, 1, 1, P(dw2), 6, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)
+
+
+def test_wgrad_f16x3_upsample_concat(cuda):
+    """decoder conv1's weight gradient on the fp16x3 kernel: cat(nearest_x2(d), skip) with the concat boundary on a 32-channel tile."""
+    L = lib()
+    g = torch.Generator().manual_seed(7)
+    n, c0, c1, cout, h, w = 2, 64, 32, 32, 8, 16
+    d = torch.randn(n, c0, h, w, generator=g)
+    sk = torch.randn(n, c1, 2 * h, 2 * w, generator=g)
+    sc0, sh0 = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    a0 = torch.relu(d * sc0[:, None, None] + sh0[:, None, None])
+    xin = torch.cat([F.interpolate(a0, scale_factor=2, mode="nearest"), sk], 1)
+    wt = (torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05).requires_grad_()
+    y = F.conv2d(xin, wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g) * 1e-4
+    y.backward(dy)
+    dd, skd, dyd = nhwc(d).to(cuda), nhwc(sk).to(cuda), nhwc(dy).to(cuda)
+    kpad = rup(9 * (c0 + c1), 32)
+    dw = torch.zeros(cout, kpad, device=cuda)
+    sc0d, sh0d = sc0.to(cuda), sh0.to(cuda)
+    s0, s1 = src(dd, sc0d, sh0d, relu=1, up=1), src(skd)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), C.byref(s1), P(dyd), n, 2 * h, 2 * w, cout, cout, kpad, 3, 3, 1, 1, P(dw), 6, stream()))
+    torch.cuda.synchronize()
+    got = unpack_w(dw.cpu(), cout, c0 + c1, 3, 3)
+    assert (got - wt.grad).abs().max() < 3e-5 * float(wt.grad.abs().max())

@@ -360,6 +360,257 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- 8-wave variant: MMA waves and loader waves
+// The 4-wave kernel above serialises, inside every wave, the staging of the next chunk (global loads, lazy BatchNorm + ReLU, the
+// hi / lo split, LDS stores: ~14 us of a 71-us layer1 launch by the compile-time ablations) with the MFMAs of the current one.
+// Here ONE 512-thread workgroup per CU gives each SIMD an MMA wave and a LOADER wave: waves 0-3 only read fragments and issue
+// MFMAs (same tiling), waves 4-7 only stage — chunk c+1 into the other buffer while chunk c is multiplied, with the global
+// loads of chunk c+2 already in flight in a second register set (two chunks of latency budget).  One barrier per chunk.
+// All eight waves share the epilogue (32 pixels x 64 channels each).
+__global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];      // [2][324 px][40 halfs]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_mma = wave < 4;
+  const int mw = wave & 3;                            // MMA wave index / loader wave index
+  const int ltid = tid & 255;                         // thread index inside its role
+  const int px16 = lane & 15, g = lane >> 4;
+
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesN = (a.Cout + 63) / 64;
+  const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
+  const int tn = tile % tilesN; tile /= tilesN;
+  const int tw = tile % tilesW; tile /= tilesW;
+  const int th = tile % tilesH; const int n = tile / tilesH;
+  const int n0 = tn * 64, h0 = th * kFT, w0 = tw * kFT;
+  const int nJ = a.wu_ncb;
+  const int nchunk = a.Ctot >> 4, nsteps = nchunk * kFKs;
+
+  float xs = 1.f;
+  if (a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
+
+  f4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  if (!is_mma) {
+    // ================= loader waves =================
+    unsigned geo[kFRounds];
+#pragma unroll
+    for (int rd = 0; rd < kFRounds; ++rd) {
+      const int u = rd * 256 + ltid;
+      const bool act = u < kFPP * 4;
+      const int pp = act ? (u >> 2) : 0;
+      const int py = pp / kFP, pxx = pp - py * kFP;
+      const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
+      const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+      geo[rd] = ((unsigned)hc << 16) | (unsigned)wc | (ok ? 0x80000000u : 0u) | (act ? 0x00008000u : 0u);
+    }
+    struct Stage { f4 pv[kFRounds]; f4 sc, sh; int relu; bool has; };
+    auto patch_load = [&](int cc, Stage& st) {
+      const int c = cc * 16;
+      const bool first = c < a.C0;
+      const Src& s = first ? a.s0 : a.s1;
+      st.relu = s.relu;
+      const int cl = (first ? c : c - a.C0) + (ltid & 3) * 4;
+      st.has = s.scale != nullptr;
+      if (st.has) { st.sc = *(const f4*)(s.scale + cl); st.sh = *(const f4*)(s.shift + cl); }
+      const float* sp = s.ptr + cl;
+#pragma unroll
+      for (int rd = 0; rd < kFRounds; ++rd) {
+        const int hc = (int)((geo[rd] >> 16) & 0x7fffu), wc = (int)(geo[rd] & 0x7fffu);
+        const size_t off = (((size_t)n * s.H + (hc >> s.up)) * s.W + (wc >> s.up)) * s.C;
+        st.pv[rd] = *(const f4*)(sp + off);
+      }
+    };
+    auto patch_store = [&](int buf, const Stage& st) {
+#pragma unroll
+      for (int rd = 0; rd < kFRounds; ++rd) {
+        f4 v = st.pv[rd];
+        if (st.has) {
+          v = v * st.sc + st.sh;
+          if (st.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        v = v * xs;
+        if (!(geo[rd] & 0x80000000u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+        if (geo[rd] & 0x00008000u) {
+          h4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = clamp_h(v[e]);
+            const _Float16 h = (_Float16)x;
+            hi[e] = h; lo[e] = (_Float16)(x - (float)h);
+          }
+          const int u = rd * 256 + ltid;
+          _Float16* d = hsm + buf * kFBuf + (u >> 2) * kFPix + (u & 3) * 4;
+          *(h4*)d = hi;
+          *(h4*)(d + 16) = lo;
+        }
+      }
+    };
+    Stage sA, sB;
+    patch_load(0, sA);
+    patch_load(nchunk > 1 ? 1 : 0, sB);
+    patch_store(0, sA);
+    __syncthreads();                                       // chunk 0 staged
+    // iteration c (two per loop trip: static register sets): store chunk c+1 (loaded one iteration ago), load chunk c+2
+    for (int cc = 0; cc < nchunk; cc += 2) {
+      {                                                    // c = cc: chunk c+1 sits in sB
+        const int c2 = cc + 2 < nchunk ? cc + 2 : nchunk - 1;
+        if (cc + 1 < nchunk) patch_store(1, sB);
+        patch_load(c2, sA);
+        __syncthreads();
+      }
+      {                                                    // c = cc + 1: chunk c+1 = cc+2 sits in sA
+        const int c3 = cc + 3 < nchunk ? cc + 3 : nchunk - 1;
+        if (cc + 2 < nchunk) patch_store(0, sA);
+        patch_load(c3, sB);
+        __syncthreads();
+      }
+    }
+  } else {
+    // ================= MMA waves =================
+    const _Float16* const wb = (const _Float16*)a.wu + (size_t)(n0 / 16) * 1024 + lane * 8;
+    auto w_load = [&](int t, h8 (&whi)[4], h8 (&wlo)[4]) {
+      const _Float16* p = wb + (size_t)t * nJ * 1024;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { whi[j] = *(const h8*)(p + j * 1024); wlo[j] = *(const h8*)(p + j * 1024 + 512); }
+    };
+    const int pbase = ((mw * 4) * kFP + px16) * kFPix + (g & 1) * 8;
+    const int ghi = g >> 1;
+    auto x_load = [&](int ks, const _Float16* pc, h8 (&xh)[4], h8 (&xl)[4]) {
+      const int slot0 = 2 * ks, slot1 = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;
+      const int off0 = ((slot0 / 3) * kFP + slot0 % 3) * kFPix, off1 = ((slot1 / 3) * kFP + slot1 % 3) * kFPix;
+      const _Float16* pp = pc + pbase + (ghi ? off1 : off0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xh[i] = *(const h8*)(pp + i * kFP * kFPix); xl[i] = *(const h8*)(pp + i * kFP * kFPix + 16); }
+    };
+    auto mma = [&](const h8 (&whi)[4], const h8 (&wlo)[4], const h8 (&xh)[4], const h8 (&xl)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+    };
+    h8 wA_hi[4], wA_lo[4], wB_hi[4], wB_lo[4], xh[4], xl[4];
+    w_load(0, wA_hi, wA_lo);
+    __syncthreads();                                       // chunk 0 staged
+    for (int cc = 0; cc < nchunk; cc += 2) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int c = cc + hh;
+        const _Float16* pc = hsm + hh * kFBuf;             // (nchunk is even: chunk c sits in buffer c & 1 = hh)
+#pragma unroll
+        for (int ks = 0; ks < kFKs; ++ks) {
+          const int t = c * kFKs + ks;
+          const int tnext = t + 1 < nsteps ? t + 1 : t;
+          // the next tap pair's filter loads and this one's fragment reads are ISSUED before the MFMA block (the fence keeps hipcc
+          // from sinking the loads behind the MFMAs to save registers: that exposed their latency at every step)
+          x_load(ks, pc, xh, xl);
+          if (((hh * kFKs + ks) & 1) == 0) { w_load(tnext, wB_hi, wB_lo); __builtin_amdgcn_sched_barrier(0); mma(wA_hi, wA_lo, xh, xl); }
+          else { w_load(tnext, wA_hi, wA_lo); __builtin_amdgcn_sched_barrier(0); mma(wB_hi, wB_lo, xh, xl); }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---------------- epilogue (conv_f16x3_kernel's, spread over eight waves): an MMA wave's 64 px x 64 ch block goes through its
+  // LDS region; waves w and w + 4 read back its pixels [0, 32) and [32, 64) with lanes along the channels
+  constexpr int kQLd = 68;
+  if (is_mma) {
+    float* const Rw = (float*)hsm + mw * 64 * kQLd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f4*)(Rw + (i * 16 + px16) * kQLd + j * 16 + g * 4) = acc[i][j];
+  }
+  __syncthreads();
+  const float* const R = (const float*)hsm + mw * 64 * kQLd;
+  const float* rinv = (const float*)a.wu + a.wu_rinv_off;
+  const float ixs = 1.f / xs;
+  const bool do_stats = a.ssum != nullptr;
+  const bool bnb = a.bnb_mean != nullptr;
+  const int cq = lane & 15, sub = lane >> 4;
+  const int co = n0 + cq * 4;
+  const bool cok = co < a.Cout;
+  const int phalf = (wave >> 2) * 32;                      // this wave's half of the block's 64 pixels
+  f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
+  {
+    f4 rs = {0.f, 0.f, 0.f, 0.f}, bmu = rs, brs = rs, bia = rs, msc = {1.f, 1.f, 1.f, 1.f}, msh = rs;
+    if (cok) rs = *(const f4*)(rinv + co) * ixs;
+    if (bnb && cok) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
+    if (a.bias && cok) bia = *(const f4*)(a.bias + co);
+    if (a.mscale && cok) { msc = *(const f4*)(a.mscale + co); msh = *(const f4*)(a.mshift + co); }
+#pragma unroll 4
+    for (int r = 0; r < 8; ++r) {
+      const int p = phalf + r * 4 + sub;
+      const int ho = h0 + mw * 4 + (p >> 4), wo = w0 + (p & 15);
+      if (ho < a.Ho && wo < a.Wo && cok) {
+        const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
+        f4 v = *(const f4*)(R + p * kQLd + cq * 4) * rs + bia;
+        if (a.addend) v += *(const f4*)(a.addend + o);
+        f4 yr = {0.f, 0.f, 0.f, 0.f};
+        if (a.mask) {
+          f4 mk = *(const f4*)(a.mask + o);
+          yr = mk;
+          if (a.mscale) mk = mk * msc + msh;
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        *(f4*)(a.out + o) = v;
+        if (a.bnb_y) yr = *(const f4*)(a.bnb_y + o);
+        ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
+      }
+    }
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sv = ps_[e], qv = pq_[e];
+      sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
+      sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+      ps_[e] = sv; pq_[e] = qv;
+    }
+    __syncthreads();                             // every wave is done with the blocks
+    float* red = (float*)hsm;                    // [8 waves][64][2]
+    if (sub == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(wave * 64 + cq * 4 + e) * 2] = ps_[e]; red[(wave * 64 + cq * 4 + e) * 2 + 1] = pq_[e]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int c1 = n0 + tid;
+      if (c1 < a.Cout) {
+        double sv = 0.0, qv = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { sv += (double)red[(w * 64 + tid) * 2]; qv += (double)red[(w * 64 + tid) * 2 + 1]; }
+        const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
+        atomicAdd(a.ssum + srep_off + c1, sv);
+        atomicAdd(a.ssq + srep_off + c1, qv);
+      }
+    }
+  }
+}
+
 // 3x3 / stride 1 / pad 1, 16-channel chunks in pairs on either side of a concat, whole 16x16 tiles not required (edges are
 // masked) but at least one; no fused concat split (ConvArgs::out_up stays on conv_wino_kernel)
 bool conv_f16x3_applicable(const ConvArgs& a) {
@@ -378,7 +629,20 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st) {
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(42, a.flops, a.bytes, conv_f16x3_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+  // 8-wave kernel (one workgroup per CU, loader waves beside the MMA waves) for launches with fewer than two workgroups per CU
+  // — long-K deep layers, where staging under the MFMAs pays (layer3 93 -> 79 us, layer4 159 -> 124, 768 -> 256 at 32^2 226 -> 198);
+  // the 4-wave kernel (two workgroups per CU hide each other's prologue and epilogue) for the many-tile, short-K ones
+  // (layer1 89 vs 93 us, layer2 73 vs 77)
+  static const bool force4 = dbg_flag("UWM_F16X3_4WAVE"), force8 = dbg_flag("UWM_F16X3_8WAVE");
+  const long wgs = (long)a.N * tilesH * tilesW * tilesN;
+  const bool four = force4 || (!force8 && wgs >= 2L * device_cu_count());
+  if (four) {
+    UWM_LAUNCH(42, a.flops, a.bytes, conv_f16x3_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
+  static DevOnce lds_attr_s;
+  { hipError_t e = lds_attr_s.set_max_lds((const void*)conv_f16x3s_kernel, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(42, a.flops, a.bytes, conv_f16x3s_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 

@@ -742,6 +742,25 @@ hipError_t launch_sumsq(const float* g, size_t n, double* out, hipStream_t st) {
 __global__ void scale_kernel(float* __restrict__ p, size_t n, float s) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] *= s;
 }
+__global__ __launch_bounds__(256) void absmax32_kernel(const float* __restrict__ x, size_t n, float* out32) {
+  __shared__ float wmax[4];
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (mx > 0.f) atomicMax((unsigned*)out32 + (blockIdx.x & 31), __float_as_uint(mx));
+  }
+}
+hipError_t launch_absmax32(const float* x, size_t n, float* out32, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(out32, 0, 32 * sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(absmax32_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, st, x, n, out32);
+  return hipGetLastError();
+}
 hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st) {
   hipLaunchKernelGGL(scale_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, p, n, s);
   return hipGetLastError();
@@ -805,7 +824,7 @@ const char* prof_class_name(int cls) {
       "wgrad_head_kernel",              "conv_up2_kernel",                "conv_up2_dgrad_kernel",
       "wgrad_up2_kernel",               "conv_gemm_kernel<128>",          "conv_gemm_kernel<64>",
       "wgrad_gemm_kernel<128>",         "wgrad_gemm_kernel<64>",          "wgrad_stem_kernel",
-      "conv_f16x3_kernel"};
+      "conv_f16x3_kernel",              "wgrad_f16x3_kernel"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

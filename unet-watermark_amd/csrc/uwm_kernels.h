@@ -120,13 +120,15 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   double flops;              // algorithmic FLOPs of this launch (host-side profiling only)
   double bytes;              // algorithmic HBM bytes of this launch: every operand read once + the output written once (profiling only)
   int wino;                  // as ConvArgs::wino
+  int prec;                  // 2: fp16x3 direct weight gradient (wgrad_f16x3.hip) where applicable; 0: fp32 kernels
+  const float* xmax;         // prec 2: 32 device floats whose maximum is max|dy| (written by bn_bwd_apply): dY is staged times the power of two that puts it in [2^13, 2^14)
   ReduceQueue* rq;           // HOST pointer (never read on the device) or nullptr: queue the partial-sum reduce instead of launching it
 };
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 43 };   // 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 44 };   // 43 = wgrad_f16x3 ; 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -161,6 +163,8 @@ bool wgrad_c16_applicable(const WgradArgs& a);              // 16-channel full-r
 hipError_t launch_wgrad_c16(const WgradArgs& a, hipStream_t st);
 hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st, ReduceQueue* rq = nullptr);      // dw += sum of nsplit full-size partial images, fixed order; rq: queued, not launched
 hipError_t launch_wgrad_reduce_multi(ReduceQueue& q, hipStream_t st);        // every queued job in one launch; empties the queue
+bool wgrad_f16x3_applicable(const WgradArgs& a);            // fp16x3 direct weight gradient of the 3x3 / stride-1 layers (wgrad_f16x3.hip); needs a.xmax
+hipError_t launch_wgrad_f16x3(const WgradArgs& a, hipStream_t st);
 bool wgrad_stem_applicable(const WgradArgs& a);             // 7x7 / stride-2 / 3(4)-channel stem: compact-column wgrad (wgrad_stem.hip)
 hipError_t launch_wgrad_stem(const WgradArgs& a, hipStream_t st);
 bool wgrad_gemm_applicable(const WgradArgs& a);             // 1x1 / stride-1 weight gradient as a persistent LDS-DMA GEMM (wgrad_gemm.hip)
@@ -259,6 +263,7 @@ hipError_t launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, 
 hipError_t launch_resize_threshold(const float* logits, int ld, int N, int h, int w, int H, int W, float thr,
                                    int apply_sigmoid, uint8_t* out, float* out_f, hipStream_t st);
 hipError_t launch_scale(float* p, size_t n, float s, hipStream_t st);
+hipError_t launch_absmax32(const float* x, size_t n, float* out32, hipStream_t st);      // out32[0..31] <- max|x| (slot workgroup & 31; zeroed first): the xmax contract of the fp16x3 kernels
 hipError_t launch_preprocess_u8(const uint8_t* img, int N, int H, int W, int C, const float* mean, const float* std,
                                 const int* flags, float* out, hipStream_t st);
 hipError_t launch_preprocess_mask(const uint8_t* m, int N, int H, int W, int thr, const int* flags, uint8_t* out, hipStream_t st);

@@ -502,6 +502,14 @@ static bool f3d_plain(const uwm_model* m, int ci) {
   for (auto& nd : m->nodes) if (nd.c1 == ci) return false;
   return true;
 }
+// fp16x3 weight gradient: rows of whole 32-pixel k-steps, 4-row stages, 32-channel tiles on either side of the concat; at most 256
+// input channels (a workgroup owns 64 x 32 channels of dW: wider layers re-read dY once per 32 input channels and the
+// Winograd-domain kernel stays ahead: 296 vs 320 us on 384 -> 128 at 64^2, profiles/r03_*_time_wgrad_f16x3.txt)
+static bool f3_wgrad_on(const uwm_model* m, size_t ci) {
+  const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
+  return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP && cv.CinP <= 256 &&
+         (p.ow[ci] % 32) == 0 && (p.oh[ci] % 4) == 0 && p.ow[ci] >= 32 && !dbg_flag("UWM_NO_F16X3_WGRAD");
+}
 static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec != UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
@@ -617,6 +625,7 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
                    (double)cv.Cout * cv.Kpad);
   a.wino = c.m->plan.wino_mode + 1;
+  if (f3_wgrad_on(c.m, (size_t)ci)) { a.prec = 2; a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off()); }
   // partial images of a split launch: the next free slice of the scratch; their reduce is queued and runs with the other layers'
   // in one launch (flush_reduces: when the scratch / queue fills up and at the end of every backward stage)
   static const bool no_defer = dbg_flag("UWM_NO_DEFER_REDUCE");
@@ -667,7 +676,7 @@ static hipError_t run_bn_bwd(const Ctx& c, int ci, const float* g, float* dy, si
     if (cs == hipStreamCaptureStatusNone) done = m->ev_disp;          // (a capturing stream takes the plain record / wait pair: graph edges)
   }
   hipError_t e = hipSuccess;
-  float* xmax = f3_dgrad_on(m, (size_t)ci) ? (float*)c.D(b.xmax_off()) : nullptr;      // the fp16x3 dgrad of this conv scales dy by its maximum
+  float* xmax = (f3_dgrad_on(m, (size_t)ci) || f3_wgrad_on(m, (size_t)ci)) ? (float*)c.D(b.xmax_off()) : nullptr;      // the fp16x3 dgrad / wgrad of this conv scale dy by its maximum
   if (sums_fused)
     e = launch_bn_bwd_apply(g, y, f, f + b.C, m->params + b.g_off, nullptr, nullptr, dy, m->grads + b.g_off, m->grads + b.b_off,
                             npix, b.C, c.st, c.D(b.d_off) + 2 * b.C, b.nrep, 2 * b.C, done, xmax);
@@ -1688,6 +1697,12 @@ int uwm_op_wgrad(const uwm_src* s0, const uwm_src* s1, const float* dy, int N, i
   a.Hl = a.s0.H << a.s0.up; a.Wl = a.s0.W << a.s0.up; a.stride = stride; a.pad = pad;
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
   a.force_igemm = force_igemm;
+  if ((force_igemm & 0xff) == 6) {               // fp16x3 direct weight gradient (tests / timing): max|dy| through a one-off reduction
+    static float* xm = nullptr;
+    if (!xm) HIPCHK(hipMalloc((void**)&xm, 32 * sizeof(float)));
+    LCHK(launch_absmax32(dy, (size_t)N * Ho * Wo * Cout, xm, (hipStream_t)stream));
+    a.prec = 2; a.xmax = xm;
+  }
   LCHK(launch_wgrad(a, (hipStream_t)stream));
   return 0;
 }

@@ -1,0 +1,290 @@
+// fp16x3 weight gradient of the 3x3 / stride-1 convolutions for gfx950 on v_mfma_f32_16x16x32_f16 (the arithmetic of
+// conv_f16x3.hip: every fp32 operand split into two fp16 halves, three MFMAs per product block, fp32 accumulation; dY scaled
+// by the power of two that puts its maximum — tracked by bn_bwd_apply — into [2^13, 2^14), X staged as it is):
+//
+//   dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p + tap][ci]         (direct form, 9 taps, pixels = the MFMA K dimension)
+//
+// The reduction runs over PIXELS, so both MFMA operands are needed k-major (8 consecutive pixels per lane) while NHWC memory
+// and its LDS image are channel-major: the fragments are read with gfx950's transposing LDS load ds_read_b64_tr_b16 (a 4 x 16
+// block of halfs per 16 lanes, delivered column-major) — no transposing stores, and a tap shift is just another row address.
+//
+// Work split: one 768-thread workgroup per CU owns 64 output channels x 32 input channels x 9 taps of dW (72 accumulator VGPRs
+// per MMA lane) and walks its share of the image in stages of 4 rows x 32 pixels:
+//   * waves 4-11 (LOADERS; twice the MMA waves: staging — index arithmetic, the lazy transform, the split — is what bounds
+//     the kernel with four of them: 87 -> 43 us on layer1 by the compile-time ablation) stage dY [128 px][hi 64 co | lo 64 co] (256-byte rows, 16-byte chunks XOR-swizzled so that the
+//     transposed reads are conflict-free) and the 6 x 34-pixel halo patch of X [204 px][hi 32 ci | lo 32 ci] (136-byte rows)
+//     with the lazy BatchNorm + ReLU / nearest x2 upsample / concat transform and the hi / lo split, double-buffered, with the
+//     global loads of the stage after next already in flight;
+//   * waves 0-3 (MMA) = (output-channel pair, input-channel fragment): per pixel row (one k-step of 32 pixels) 2 dY fragments
+//     and, per tap, one X fragment (2 transposed reads per half) feeding 6 MFMAs; 54 MFMAs per k-step;
+//   * one barrier per stage.  Pixel splits store dW-shaped partial images, wgrad_reduce adds them in a fixed order
+//     (deterministic; same queue as the Winograd weight gradient).
+//
+// Replaces the weight-gradient half of autograd's conv2d backward for these layers.
+#include "uwm_kernels.h"
+
+namespace uwm {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
+
+#ifndef UWM_WG16_ABL
+#define UWM_WG16_ABL 0      // compile-time timing ablations (scripts/ablate_f16x3.sh wgrad ...): 1 no MFMA, 2 no X fragment reads, 4 no loader work after the first stage; 0 in the product build
+#endif
+constexpr int kWR = 4, kWX = 32, kWPW = kWX + 2, kWPH = kWR + 2;      // stage = 4 rows x 32 pixels; halo patch 6 x 34
+constexpr int kWDyB = kWR * kWX * 256;                                // bytes of a dY stage image (32 768)
+constexpr int kWXS = 136;                                              // bytes per X patch pixel (128 + 8 pad)
+constexpr int kWXB = kWPH * kWPW * kWXS;                               // bytes of an X stage image (27 744)
+constexpr int kWStage = kWDyB + ((kWXB + 255) & ~255);                 // bytes per stage buffer
+constexpr int kWLT = 512;                                              // loader threads (8 waves) next to the 4 MMA waves
+constexpr int kWDyRounds = kWR * kWX * 16 / kWLT;                      // dY 16-byte units per loader thread: 4
+constexpr int kWXRounds = (kWPH * kWPW * 8 + kWLT - 1) / kWLT;         // X units per loader thread: 4
+
+__device__ __forceinline__ int off_dy(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ float clamp_hw(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ h8 tr_pair(const char* base, int o0, int o1) {      // two transposed reads -> one 8-half operand fragment
+  const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(uintptr_t)(base + o0));
+  const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(uintptr_t)(base + o1));
+  typedef __fp16 fp16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+  const fp16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(h8, v);
+}
+
+__global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, int stages_per_split, int nstages) {
+  extern __shared__ __attribute__((aligned(256))) char wsm[];       // [2][dY image | X image]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_mma = wave < 4;
+  const int ltid = tid - 256;                          // loader thread index (waves 4-11)
+
+  const int tilesA = (a.wrows + 63) / 64, tilesB = a.Ctot / 32;
+  const int pairs = tilesA * tilesB;
+  const int split = blockIdx.x / pairs, pr = blockIdx.x - split * pairs;
+  const int ta = pr / tilesB, tb = pr - ta * tilesB;
+  const int a0 = ta * 64, b0 = tb * 32;
+  const int st0 = split * stages_per_split, st1 = min(nstages, st0 + stages_per_split);
+  const int tilesX = a.Wo / kWX, tilesY = a.Ho / kWR;
+
+  float xs = 1.f;                                      // power-of-two scale of dY (conv_f16x3.hip)
+  if (a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
+
+  f4 acc[2][9];
+#pragma unroll
+  for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[cf][t] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  if (!is_mma) {
+    // ================= loader waves =================
+    const bool first = b0 < a.C0;                      // the workgroup's 32 input channels lie in one source of the concat
+    const Src& s = first ? a.s0 : a.s1;
+    const int cl = first ? b0 : b0 - a.C0;
+    // dY unit (round rd): pixel = (rd * 256 + ltid) >> 4, channel quad = ltid & 15
+    const int dcu = ltid & 15;
+    const bool dok = a0 + dcu * 4 < a.Cout;
+    // X unit (round rd): patch pixel = (rd * 256 + ltid) >> 3, channel quad = ltid & 7
+    const int xcu = ltid & 7;
+    f4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+    const bool xhas = s.scale != nullptr;
+    if (xhas) { xsc = *(const f4*)(s.scale + cl + xcu * 4); xsh = *(const f4*)(s.shift + cl + xcu * 4); }
+    const int xrelu = s.relu;
+    struct Stage { f4 dv[kWDyRounds]; f4 xv[kWXRounds]; unsigned xok; };
+    auto stage_load = [&](int st, Stage& sg) {
+      int q = st;
+      const int tx = q % tilesX; q /= tilesX;
+      const int ty = q % tilesY; const int n = q / tilesY;
+      const int y0 = ty * kWR, x0 = tx * kWX;
+#pragma unroll
+      for (int rd = 0; rd < kWDyRounds; ++rd) {
+        const int px = (rd * kWLT + ltid) >> 4;
+        const size_t o = (((size_t)n * a.Ho + y0 + (px >> 5)) * a.Wo + x0 + (px & 31)) * a.Cout + a0 + dcu * 4;
+        sg.dv[rd] = dok ? *(const f4*)(a.dy + o) : (f4){0.f, 0.f, 0.f, 0.f};
+      }
+      sg.xok = 0;
+#pragma unroll
+      for (int rd = 0; rd < kWXRounds; ++rd) {
+        const int pp = (rd * kWLT + ltid) >> 3;
+        const bool act = pp < kWPH * kWPW;
+        const int py = act ? pp / kWPW : 0, px = act ? pp - py * kWPW : 0;
+        const int hl = y0 - 1 + py, wl = x0 - 1 + px;
+        const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+        const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+        const size_t o = (((size_t)n * s.H + (hc >> s.up)) * s.W + (wc >> s.up)) * s.C + cl + xcu * 4;
+        sg.xv[rd] = *(const f4*)(s.ptr + o);
+        sg.xok |= (ok ? 1u : 0u) << rd;
+      }
+    };
+    auto split_store = [&](char* dst_hi, char* dst_lo, f4 v) {
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = clamp_hw(v[e]);
+        const _Float16 h = (_Float16)x;
+        hi[e] = h; lo[e] = (_Float16)(x - (float)h);
+      }
+      *(h4*)dst_hi = hi; *(h4*)dst_lo = lo;
+    };
+    auto stage_store = [&](int buf, const Stage& sg) {
+      char* const dyb = wsm + buf * kWStage;
+      char* const xb = dyb + kWDyB;
+#pragma unroll
+      for (int rd = 0; rd < kWDyRounds; ++rd) {
+        const int px = (rd * kWLT + ltid) >> 4;
+        const int o = off_dy(px, dcu >> 1) + (dcu & 1) * 8;
+        split_store(dyb + o, dyb + (o ^ 128), sg.dv[rd] * xs);        // lo plane: chunk + 8 (bit 3 of the swizzled chunk index)
+      }
+#pragma unroll
+      for (int rd = 0; rd < kWXRounds; ++rd) {
+        const int pp = (rd * kWLT + ltid) >> 3;
+        if (pp < kWPH * kWPW) {
+          f4 v = sg.xv[rd];
+          if (xhas) {
+            v = v * xsc + xsh;
+            if (xrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          }
+          if (!((sg.xok >> rd) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+          char* d = xb + pp * kWXS + xcu * 8;
+          split_store(d, d + 64, v);
+        }
+      }
+    };
+    Stage sA, sB;
+    const int ns = st1 - st0;
+    if (ns > 0) {
+      stage_load(st0, sA);
+      stage_load(ns > 1 ? st0 + 1 : st0, sB);
+      stage_store(0, sA);
+    }
+    __syncthreads();
+    constexpr bool skip = (UWM_WG16_ABL & 4) != 0;
+    for (int i = 0; i < ns; i += 2) {
+      {                                                  // stage i is being multiplied; stage i+1 (in sB) goes to buffer 1
+        if (i + 1 < ns && !(skip && i > 0)) stage_store(1, sB);
+        if (!skip) stage_load(st0 + (i + 2 < ns ? i + 2 : ns - 1), sA);
+        __syncthreads();
+      }
+      if (i + 1 < ns) {
+        if (i + 2 < ns && !skip) stage_store(0, sA);
+        if (!skip) stage_load(st0 + (i + 3 < ns ? i + 3 : ns - 1), sB);
+        __syncthreads();
+      }
+    }
+  } else {
+    // ================= MMA waves: (output-channel pair cp, input-channel fragment bf) =================
+    const int cp = wave & 1, bf = wave >> 1;
+    const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    // dY fragment addresses (bytes inside a dY image) for pixel row 0 of the stage: rows 8*kg + q (+4), chunks 2*(2cp+cf) + (p>>1) (+8 lo)
+    int dyo[2][2];                                       // [cf][read]; the lo plane is the same address with bit 7 flipped (chunk + 8)
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+      for (int rdx = 0; rdx < 2; ++rdx)
+        dyo[cf][rdx] = off_dy(8 * kg + 4 * rdx + q, 2 * (2 * cp + cf) + (p >> 1)) + 8 * (p & 1);
+    // X fragment base (bytes inside an X image): patch pixel (row 0, column 8*kg + q), chunk 2*bf + (p>>1)
+    const int xo = (8 * kg + q) * kWXS + (2 * bf + (p >> 1)) * 16 + 8 * (p & 1);
+    const int ns = st1 - st0;
+    __syncthreads();
+    for (int i = 0; i < ns; ++i) {
+      const char* const dyb = wsm + (i & 1) * kWStage;
+      const char* const xb = dyb + kWDyB;
+#pragma unroll
+      for (int kr = 0; kr < kWR; ++kr) {
+        h8 ah[2], al[2];
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) {
+          ah[cf] = tr_pair(dyb + kr * kWX * 256, dyo[cf][0], dyo[cf][1]);
+          al[cf] = tr_pair(dyb + kr * kWX * 256, dyo[cf][0] ^ 128, dyo[cf][1] ^ 128);
+        }
+        // Iteration it: the X fragments of tap it+1 are read (one tap ahead of their first use), hh of tap it and hl, lh of tap
+        // it-1 are issued, interleaved over the two channel fragments so that the three products of a tile — they update the SAME
+        // accumulator — sit at least two issue slots apart.  The fence keeps hipcc from hoisting every tap's reads to the top
+        // of the k-step (144 VGPRs of fragments: spills).
+        h8 xh[3], xl[3];
+        auto x_read = [&](int t) {
+          const int r = t / 3, sx = t % 3;
+          const char* xp = xb + ((kr + r) * kWPW + sx) * kWXS + xo;
+          xh[t % 3] = (UWM_WG16_ABL & 2) ? ah[0] : tr_pair(xp, 0, 4 * kWXS);
+          xl[t % 3] = (UWM_WG16_ABL & 2) ? al[1] : tr_pair(xp, 64, 4 * kWXS + 64);
+        };
+        x_read(0);
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+          if (it + 1 < 9) x_read(it + 1);
+          if (UWM_WG16_ABL & 1) { if (it < 9) { acc[0][it][0] += (float)xh[it % 3][0] + (float)xl[it % 3][1]; acc[1][it][1] += (float)ah[1][2] + (float)al[0][3]; } continue; }
+          const int pt = it - 1, ps = (it + 2) % 3, cs = it % 3;
+          if (it < 9) acc[0][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], xh[cs], acc[0][it], 0, 0, 0);
+          if (it >= 1) acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], xl[ps], acc[0][pt], 0, 0, 0);
+          if (it < 9) acc[1][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], xh[cs], acc[1][it], 0, 0, 0);
+          if (it >= 1) acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], xl[ps], acc[1][pt], 0, 0, 0);
+          if (it >= 1) acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], xh[ps], acc[0][pt], 0, 0, 0);
+          if (it >= 1) acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], xh[ps], acc[1][pt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- D[row = co 4*(lane>>4) + reg][col = ci lane & 15] of tile (cf, tap) -> this split's partial image (or dW itself)
+    const float ixs = 1.f / xs;
+    float* const dst = a.nsplit > 1 ? a.part + (size_t)split * a.wrows * a.Kpad : a.dw;
+    const int ci = b0 + 16 * bf + (lane & 15);
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = a0 + 16 * (2 * cp + cf) + 4 * (lane >> 4) + e;
+          if (row < a.wrows && ci < a.Ctot) {
+            float* pd = dst + (size_t)row * a.Kpad + t * a.Ctot + ci;
+            const float v = acc[cf][t][e] * ixs;
+            if (a.nsplit > 1) *pd = v; else *pd += v;
+          }
+        }
+  }
+}
+
+// 3x3 / stride 1 / pad 1, input channels in whole 32-channel tiles on either side of the concat, image rows of whole 32-pixel
+// k-steps and 4-row stages, dY scaled through a.xmax
+bool wgrad_f16x3_applicable(const WgradArgs& a) {
+  return a.xmax != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
+         (a.Cout & 3) == 0 && a.wrows <= a.Cout && a.Kpad == 9 * a.Ctot && a.Hl == a.Ho && a.Wl == a.Wo &&
+         (a.Wo % kWX) == 0 && (a.Ho % kWR) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0;
+}
+
+hipError_t launch_wgrad_f16x3(const WgradArgs& a0, hipStream_t st) {
+  WgradArgs a = a0;
+  if (!wgrad_f16x3_applicable(a)) return hipErrorInvalidValue;
+  const int pairs = ((a.wrows + 63) / 64) * (a.Ctot / 32);
+  const int nstages = a.N * (a.Ho / kWR) * (a.Wo / kWX);
+  // one 512-thread workgroup per CU; at least 4 stages per split (the two-stage prefetch needs a few to pay)
+  const int cus = device_cu_count();
+  int nsplit = (cus + pairs - 1) / pairs;
+  if (nsplit > nstages / 4) nsplit = nstages / 4;
+  if (nsplit < 1) nsplit = 1;
+  const size_t image = (size_t)a.wrows * a.Kpad;
+  if (nsplit > 1 && (!a.part || a.part_floats < 2 * image)) { a.part = wgrad_op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); a.rq = nullptr; }
+  if (nsplit > 1 && (!a.part || (size_t)nsplit * image > a.part_floats)) nsplit = a.part ? (int)(a.part_floats / image) : 1;
+  if (nsplit < 1) nsplit = 1;
+  const int sps = (nstages + nsplit - 1) / nsplit;
+  nsplit = (nstages + sps - 1) / sps;
+  a.nsplit = nsplit; a.msplit = sps;
+  const size_t lds = (size_t)2 * kWStage;
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_f16x3_kernel, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(43, a.flops, a.bytes, wgrad_f16x3_kernel, dim3((unsigned)(pairs * nsplit)), dim3(768), lds, st, a, sps, nstages);
+  if (nsplit > 1) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_wgrad_reduce(a.part, nsplit, image / 4, a.dw, st, a.rq);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace uwm
