@@ -137,6 +137,52 @@ def test_bf16x3_precision_mode_meets_the_fp32_bars(cuda, arch, enc, n, h, w):
     assert L.lib().uwm_get_precision(m._h) == 0
 
 
+@pytest.mark.parametrize("arch,enc,n,h,w", [("Unet", "resnet18", 4, 128, 160), ("Unet", "resnet34", 2, 256, 192),
+                                            ("UnetPlusPlus", "resnet34", 2, 128, 192), ("Unet", "resnet50", 4, 128, 160),
+                                            ("Unet", "efficientnet-b4", 4, 128, 128)])
+def test_f16x3_precision_modes_meet_the_fp32_bars(cuda, arch, enc, n, h, w):
+    """uwm_set_precision(h, UWM_PREC_F16X3 | UWM_PREC_F16X3_ALL): the 3x3 stride-1 convolutions (forward; forward + data and
+    weight gradients) as direct convolutions on v_mfma_f32_16x16x32_f16 with fp16x3 split products (conv_f16x3.hip,
+    wgrad_f16x3.hip) against the fp32 CPU oracle under the SAME bars as the fp32 mode, on every encoder and both decoders —
+    with the fill threshold at 1 so that every eligible layer of these small cases really runs on the new kernels."""
+    import unet_watermark_amd as U
+    from unet_watermark_amd import _lib as L
+    from oracle import unet_oracle as O
+    m, ref = _pair(enc, dev=cuda, arch=arch)
+    if enc == "efficientnet-b4":
+        m.drop_connect = False
+    x, t = O.synthetic_batch(n, h, w, seed=7)
+    m.train(); ref.train()
+    crit_ref = O.CombinedLoss([O.BCEWithLogits(), O.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    crit = U.CombinedLoss([U.BCEWithLogitsLoss(), U.DiceLoss(smooth=1e-5)], [0.5, 0.5])
+    out_ref = ref(x); loss_ref = crit_ref(out_ref, t.unsqueeze(1)); loss_ref.backward()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m.set_precision("f32")
+    out_f32 = m(x.to(cuda)); crit(out_f32, t.unsqueeze(1).to(cuda)).backward()
+    g_f32 = m.flat_grads().clone()
+    for mode, code in (("f16x3", 3), ("f16x3_all", 4)):
+        m.load_state_dict(sd0)                                  # undo the running-statistics update of the previous forward
+        m.set_precision(mode, min_workgroups=1)
+        assert L.lib().uwm_get_precision(m._h) == code and m.precision == mode
+        for p in m.parameters():
+            p.grad = None
+        out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda)); loss.backward()
+        assert not torch.equal(out.detach(), out_f32.detach())  # the mode really changes the forward arithmetic ...
+        assert float((out.detach() - out_f32.detach()).abs().max()) < 2e-4      # ... by fp32-class rounding only
+        assert float((out.detach().cpu() - out_ref.detach()).abs().max()) < LOGIT_TOL
+        assert abs(loss.item() - loss_ref.item()) < 1e-5
+        if enc == "resnet50":
+            _grad_check(m, ref, l2_rel=7e-2, cos_min=0.9975)
+        elif enc == "efficientnet-b4":
+            _effb4_grad_check(m, ref)
+        else:
+            _grad_check(m, ref)
+        g = m.flat_grads()
+        assert not torch.equal(g, g_f32) and float((g - g_f32).norm() / g_f32.norm()) < 2e-2
+    m.set_precision("f32", min_workgroups=0)
+    assert L.lib().uwm_get_precision(m._h) == 0
+
+
 @pytest.mark.parametrize("enc,bar", [("resnet18", 1e-3), ("resnet34", 3e-3)])
 def test_bf16x3_all_forward_error_is_what_the_header_says(cuda, enc, bar):
     """UWM_PREC_BF16X3_ALL (forward products split as well) is offered outside BASELINE's parity claim: its logit error

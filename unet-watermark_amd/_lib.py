@@ -78,6 +78,7 @@ SIGNATURES = {
     "uwm_get_winograd_mode": (I, [P]),
     "uwm_set_precision": (I, [P, I]),
     "uwm_get_precision": (I, [P]),
+    "uwm_set_precision_fill": (I, [P, I]),
     "uwm_allreduce_grads": (I, [P, P, I, I, P]),
     "uwm_grad_arena": (P, [P]),
     "uwm_set_join_stream": (I, [P, P]),

@@ -134,6 +134,7 @@ struct uwm_model {
   int nstages = 5;                    // backward stages = gradient buckets (head+decoder, then four encoder groups)
   bool hwq_warned = false;
   ReduceQueue rq;                    // partial-sum reduces of the split weight gradients, flushed once per backward stage (uwm_kernels.h)
+  int f3_min_wgs = 0;                // fp16x3 kernels: smallest launch (workgroups) they take; 0 = one per CU (uwm_set_precision_fill)
   std::vector<char> out_sums;        // per residual block: the BatchNorm-backward sums of its last BatchNorm were made by the dgrad that wrote its output gradient (run_dgrad bn_y)
 };
 
@@ -493,7 +494,7 @@ static bool f3_fwd_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec < UWM_PREC_F16X3 || !cv.f3() || !p.wino_ok(ci)) return false;
   const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
-  return wgs >= device_cu_count();
+  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count());
 }
 // fp16x3 dgrads cover the plain epilogue only: a decoder conv1 (its dgrad splits the concat gradient in the epilogue: ConvArgs::out_up)
 // keeps the Winograd kernel
@@ -514,7 +515,7 @@ static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec != UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
   const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
-  return wgs >= device_cu_count();
+  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count());
 }
 // ------------------------------------------------------------------------------ launch helpers
 struct Ctx {
@@ -1598,6 +1599,10 @@ int uwm_set_precision(uwm_handle h, int mode) {
   return 0;
 }
 int uwm_get_precision(uwm_handle h) { return h ? h->prec : -1; }
+int uwm_set_precision_fill(uwm_handle h, int min_workgroups) {
+  if (!h || min_workgroups < 0) return fail("uwm_set_precision_fill: bad argument");
+  h->f3_min_wgs = min_workgroups; return 0;
+}
 
 // ---- data-parallel exchange on the C ABI: SUM all-reduce of the gradient arena ranges of backward
 // stages [stage_begin, stage_end) over an RCCL communicator, one collective per stage (= bucket), enqueued on `stream`.

@@ -228,16 +228,21 @@ class Unet(nn.Module):
     def num_parameters(self) -> int:
         return int(L.lib().uwm_param_count(self._h))
 
-    def set_precision(self, mode: str = "f32"):
+    def set_precision(self, mode: str = "f32", min_workgroups: Optional[int] = None):
         """Arithmetic of the convolution products, per model (uwm_set_precision): "f32" (default: exact fp32 matrix
         instructions); "bf16x3" (opt-in: the backward data-gradient convolutions take each product as a_hi*b_hi + a_hi*b_lo +
         a_lo*b_hi over bf16 halves of the fp32 operands, fp32 accumulation — the forward, hence every logit, is unchanged);
-        "bf16x3_all" (forward products too: 1.6e-3 logit error on resnet34, outside the 1e-3 bar on deep encoders).
+        "bf16x3_all" (forward products too: 1.6e-3 logit error on resnet34, outside the 1e-3 bar on deep encoders);
+        "f16x3" / "f16x3_all" (3x3 stride-1 convolutions — forward / forward, data and weight gradients — in direct form on
+        gfx950's v_mfma_f32_16x16x32_f16 with every fp32 operand split into two fp16 halves: 22-bit operands, fp32 accumulation,
+        power-of-two range scaling; fp32-class accuracy: the fp32 mode's parity bars hold, logit error 1.0e-4 either way).
         Parameters, activations, gradients and optimizer state stay fp32.  The reference's GPU path is reduced precision
         as well (fp16 autocast + GradScaler, /root/reference/src/train.py:75,89-98)."""
         if mode not in L.PREC:
             raise ValueError(f"unsupported precision {mode!r} (supported: {list(L.PREC)})")
         L.check(L.lib().uwm_set_precision(self._h, L.PREC[mode]), ValueError)
+        if min_workgroups is not None:       # fp16x3 modes: smallest launch the fp16x3 kernels take (default: one workgroup per CU)
+            L.check(L.lib().uwm_set_precision_fill(self._h, int(min_workgroups)), ValueError)
         self.precision = mode
         return self
 
