@@ -36,10 +36,14 @@ if ROOT not in sys.path:
 
 WINO_RATIO = 2.25            # direct-conv multiplies per Winograd F(2x2,3x3) multiply (36 / 16)
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
-BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (alt_modes only)
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (v_mfma_f32_16x16x32_{f16,bf16})
+F16X3_DTYPE = ("f32 storage and accumulation; the 3x3 stride-1 convolution products (forward, data and weight gradients) as fp16x3 "
+               "splits - every fp32 operand = two fp16 halves (22 mantissa bits), a*b = ah*bh + ah*bl + al*bh on "
+               "v_mfma_f32_16x16x32_f16, exact power-of-two range scaling; every other kernel exact fp32")
 
 
-def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Unet", batch: int = 16, decoder_channels=None):
+def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Unet", batch: int = 16, decoder_channels=None,
+                 precision: str = "f32"):
     """Oracle (torch CPU fp32) train step on this host's cores.  `value` is timed at the bench's OWN batch size (SURVEY 8d:
     the identical config-2 step, >= 3 timed steps) when one such step fits the time budget, else on a bs2 sample; the
     parity numbers (mask IoU, logits, loss, gradient cosine) always come from a bs2 sample of the same workload."""
@@ -98,6 +102,7 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
         dev = torch.device("cuda", torch.cuda.current_device())
         ref0 = O.build(encoder, seed=42, arch=arch, **kw)
         hm = getattr(U, arch)(encoder, **kw).to(dev)
+        hm.set_precision(precision)                  # the parity numbers are those of the benched precision mode
         hm.load_state_dict(ref0.state_dict())
         hm.train(); ref0.train()
         cr, ch = O.DiceLoss(smooth=1e-5), U.DiceLoss(mode="binary", smooth=1e-5)
@@ -115,9 +120,10 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
             if float(g2.norm()) > 0 and float(g1.norm()) > 0:
                 cmin = min(cmin, float(g1 @ g2 / (g1.norm() * g2.norm())))
         out["min_grad_cosine_vs_cpu_ref"] = round(cmin, 6)
-        # the opt-in precision modes on the same batch / weights / oracle run
+        out["parity_precision_mode"] = precision
+        # the other precision modes on the same batch / weights / oracle run
         alt = {}
-        for mode in ("bf16x3", "bf16x3_all"):
+        for mode in [m_ for m_ in ("f32", "f16x3_all", "bf16x3") if m_ != precision]:
             hm.load_state_dict(ref0.state_dict()); hm.set_precision(mode)
             for p_ in hm.parameters():
                 p_.grad = None
@@ -129,7 +135,7 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
                     c2 = min(c2, float(g1 @ g2 / (g1.norm() * g2.norm())))
             alt[mode] = {"logit_max_abs_err_vs_cpu_ref": float(f"{float((o2.detach().cpu() - lr_).abs().max()):.3e}"),
                          "min_grad_cosine_vs_cpu_ref": round(c2, 6)}
-        hm.set_precision("f32")
+        hm.set_precision(precision)
         out["alt_modes_parity"] = alt
     except Exception as e:                      # never let the checker break the bench line
         out["mask_iou_vs_cpu_ref"] = None
@@ -160,12 +166,16 @@ def collect_prof(L, steps):
         if cnt > 0 and ms > 0:
             name = L.lib().uwm_prof_class_name(c).decode()
             wino = "wino" in name or "up2" in name       # Winograd F(2x2,3x3) and the sub-pixel form of conv-after-upsample: the MFMA pipe executes 16 multiplies per 36 direct ones
+            f16 = "f16x3" in name                        # direct form, three half-precision MFMAs per product block: 3x the direct FLOPs on the f16 pipe
+            factor = 3.0 if f16 else (1.0 / WINO_RATIO if wino else 1.0)
             ents[name] = {"kernel": name, "launches_per_step": cnt / max(1, steps), "avg_us": round(1e3 * ms / cnt, 2),
                           "ms_per_step": round(ms / max(1, steps), 3),
-                          "mfma_tflops": round(fl / ms / 1e9 / (WINO_RATIO if wino else 1.0), 2),
+                          "mfma_tflops": round(fl * factor / ms / 1e9, 2),
+                          "mfma_pipe": "f16 (v_mfma_f32_16x16x32_f16)" if f16 else "f32 (v_mfma_f32_16x16x4_f32)",
+                          "mfma_peak_tflops": BF16_MATRIX_PEAK_TFLOPS if f16 else F32_MATRIX_PEAK_TFLOPS,
                           "algorithmic_tflops": round(fl / ms / 1e9, 2),
                           "algorithmic_bytes_per_launch": int(by / cnt), "algorithmic_GBps": round(by / ms / 1e6, 1),
-                          "_ms": ms, "_fl": fl, "_exec": fl / (WINO_RATIO if wino else 1.0)}
+                          "_ms": ms, "_fl": fl, "_exec": fl * factor, "_peak": BF16_MATRIX_PEAK_TFLOPS if f16 else F32_MATRIX_PEAK_TFLOPS}
     return ents
 
 
@@ -271,6 +281,10 @@ def main():
                          "(/root/reference/src/configs/unet_watermark_large.yaml:5-19,36) is --arch UnetPlusPlus --encoder resnet50 "
                          "--decoder-channels 1024,512,256,128,64 --size 1024 --batch 8")
     ap.add_argument("--no-ddp-check", action="store_true", help="skip the warm-up self-validation of the data-parallel exchange")
+    ap.add_argument("--precision", default="f16x3_all", choices=["f32", "f16x3", "f16x3_all", "bf16x3", "bf16x3_all"],
+                    help="precision mode of the timed steps (uwm_set_precision).  f16x3_all (default): fp16x3 split products on the "
+                         "3x3 stride-1 convolutions, fp32-class accuracy - it meets the fp32 mode's parity bars (tests); f32: every "
+                         "product on the exact-fp32 matrix instruction (reported under alt_modes otherwise)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the train step from ONE captured hipGraph (Trainer(use_graph=True); single process only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,6 +328,7 @@ def main():
     dec = tuple(int(c) for c in args.decoder_channels.split(",")) if args.decoder_channels else None
     model = getattr(U, args.arch)(args.encoder, encoder_weights=None, in_channels=3, classes=1,
                                   **({"decoder_channels": dec} if dec else {})).to(dev)
+    model.set_precision(args.precision)
     trainer = Trainer(model, w_dice=1.0, w_bce=0.0, smooth=1e-5, lr=1e-4, weight_decay=1e-4,
                       overlap_comm=not args.no_overlap, force_ddp=force_ddp and not os.environ.get("UWM_PG_ONLY"),
                       use_graph=args.graph and world == 1 and not force_ddp)
@@ -366,11 +381,11 @@ def main():
         ents_s = collect_prof(L, args.serial_steps)
         L.lib().uwm_set_side_stream(model._h, 1)
 
-    # opt-in precision modes (NOT part of `value`): the same step with uwm_set_precision(bf16x3 | bf16x3_all)
+    # the other precision modes (NOT part of `value`): the same step with uwm_set_precision(...)
     alt_modes = None
     if args.alt_steps > 0 and rank == 0 and world == 1:
         alt_modes = {}
-        for mode in ("bf16x3", "bf16x3_all"):
+        for mode in [m_ for m_ in ("f32", "f16x3_all", "bf16x3") if m_ != args.precision]:
             model.set_precision(mode)
             for _ in range(3):
                 trainer.step(x, t)
@@ -380,26 +395,12 @@ def main():
                 la = trainer.step(x, t)
             torch.cuda.synchronize(dev)
             dta = time.perf_counter() - ta
-            L.lib().uwm_prof_enable(1)
-            for _ in range(3):
-                trainer.step(x, t)
-            torch.cuda.synchronize(dev)
-            L.lib().uwm_prof_enable(0)
-            ea = collect_prof(L, 3).get("conv_wino_x3_kernel")
-            ent = {"value": round(n * args.alt_steps / dta, 2), "unit": "images/s", "ms_per_step": round(1e3 * dta / args.alt_steps, 3),
-                   "steps": args.alt_steps, "loss": round(float(la[0].item()), 6),
-                   "dtype": ("bf16x3 on the dgrad products of the 3x3 stride-1 layers (a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate); "
-                             "forward, weight gradients, BatchNorm, loss, optimizer: f32") if mode == "bf16x3" else
-                            "bf16x3 on forward AND dgrad products of the 3x3 stride-1 layers; weight gradients and the rest: f32"}
-            if ea:      # roofline of the split-bf16 kernel: 3 executed bf16 MFMA FLOPs per Winograd-domain FLOP, against the bf16 peak
-                ex = 3.0 * ea["_exec"] / ea["_ms"] / 1e9
-                ent["roofline"] = {"bound": "mfma", "kernel": "conv_wino_x3_kernel", "achieved": round(ex, 1), "peak": BF16_MATRIX_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(ex / BF16_MATRIX_PEAK_TFLOPS, 4), "avg_launch_us": ea["avg_us"],
-                                   "launches_per_step": ea["launches_per_step"], "algorithmic_tflops": ea["algorithmic_tflops"],
-                                   "note": "executed = 3 x (direct-conv FLOPs / 2.25) on v_mfma_f32_16x16x16_bf16; the kernel is bound by the "
-                                           "fp32 input transform + bf16 split on the VALU and the filter stream, not by the bf16 MFMA pipe"}
-            alt_modes[mode] = ent
-        model.set_precision("f32")
+            alt_modes[mode] = {"value": round(n * args.alt_steps / dta, 2), "unit": "images/s", "ms_per_step": round(1e3 * dta / args.alt_steps, 3),
+                               "steps": args.alt_steps, "loss": round(float(la[0].item()), 6),
+                               "dtype": {"f32": "f32: every product on the exact-fp32 matrix instruction (v_mfma_f32_16x16x4_f32)",
+                                         "f16x3_all": F16X3_DTYPE,
+                                         "bf16x3": "bf16x3 split products (16-bit operands) on the dgrads of the 3x3 stride-1 layers; the rest f32"}[mode]}
+        model.set_precision(args.precision)
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -416,7 +417,8 @@ def main():
         out = {
             "metric": "train_images_per_sec", "value": round(world * n * args.steps / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": F16X3_DTYPE if args.precision == "f16x3_all" else args.precision, "precision_mode": args.precision, "data": "synthetic",
             "config": {"workload": f"{args.arch}-{args.encoder} {s}x{s} bs{n}/GPU train step: fwd + Dice + bwd + Adam "
                                    + (f"(BASELINE.json configs[{1 if world == 1 else 2}])" if headline else
                                       "(the per-GPU workload of BASELINE.json configs[3]: SURVEY 8 a18)"
@@ -433,7 +435,7 @@ def main():
             "roofline": None,
         }
         if dom:
-            P = F32_MATRIX_PEAK_TFLOPS
+            P = dom["_peak"]               # the dominant kernel's own matrix pipe (fp32 MFMA 157.3, f16 MFMA 2500)
             alone = None
             if ents_s is not None and dom["kernel"] in ents_s:
                 a_ = ents_s[dom["kernel"]]
@@ -465,8 +467,14 @@ def main():
                 "frac": round(dom["mfma_tflops"] / P, 4),
                 "definition": "achieved = FLOPs the MFMA pipe EXECUTED per launch / average launch duration of the kernel with the "
                               "largest share of kernel time, over the profiled steps of the timed region (dispatch-attached HIP "
-                              "events on the launch stream; co-resident with the other stream's kernels); peak = fp32 MFMA "
-                              "(v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md); frac = achieved / peak (never > 1)",
+                              "events on the launch stream; co-resident with the other stream's kernels); peak = the dense peak of the "
+                              "matrix instruction THAT kernel issues (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 157.3 TF, "
+                              "v_mfma_f32_16x16x32_f16 2500 TF; an fp16x3 kernel executes 3x its direct-convolution FLOPs there, a Winograd "
+                              "kernel 1/2.25 of them on the fp32 pipe); frac = achieved / peak (never > 1)",
+                "mfma_pipe": dom["mfma_pipe"],
+                "hbm_view": {"achieved_GBps": dom["algorithmic_GBps"], "peak_GBps": 8000.0, "frac": round(dom["algorithmic_GBps"] / 8000.0, 4),
+                             "note": "algorithmic bytes (every operand once + the output once) / the same duration: the fp16x3 kernels are "
+                                     "closer to this roof than to their matrix pipe's"},
                 "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
                 "algorithmic": {"tflops": dom["algorithmic_tflops"],
                                 "note": "direct-convolution FLOPs of SURVEY.md 8(d) / the same duration; Winograd F(2x2,3x3) kernels "
@@ -474,15 +482,17 @@ def main():
                 "alone": alone,
                 # the next kernels by time in the step (the first three are within a few per cent of each other on the headline
                 # config, so which one is "dominant" can flip between runs): same definitions
-                "runners_up": [{"kernel": k["kernel"], "frac": round(k["mfma_tflops"] / P, 4), "avg_launch_us": k["avg_us"],
-                                "launches_per_step": k["launches_per_step"], "ms_per_step": k["ms_per_step"],
-                                "alone_frac": (round(ents_s[k["kernel"]]["mfma_tflops"] / P, 4)
+                "runners_up": [{"kernel": k["kernel"], "frac": round(k["mfma_tflops"] / k["_peak"], 4), "mfma_pipe": k["mfma_pipe"], "avg_launch_us": k["avg_us"],
+                                "launches_per_step": k["launches_per_step"], "ms_per_step": k["ms_per_step"], "hbm_frac": round(k["algorithmic_GBps"] / 8000.0, 4),
+                                "alone_frac": (round(ents_s[k["kernel"]]["mfma_tflops"] / k["_peak"], 4)
                                                if ents_s is not None and k["kernel"] in ents_s else None),
                                 "alone_avg_launch_us": (ents_s[k["kernel"]]["avg_us"]
                                                         if ents_s is not None and k["kernel"] in ents_s else None)}
                                for k in kernels[1:3]],
                 "step": {"mfma_tflops": round(tot_ex * 1e-9 / prof_steps / ms_step, 2),
-                         "frac": round(tot_ex * 1e-9 / prof_steps / ms_step / P, 4),
+                         "frac": round(sum(k["_exec"] / k["_peak"] for k in kernels) * 1e-9 / prof_steps / ms_step, 4),
+                         "frac_definition": "sum over conv / wgrad classes of (executed MFMA FLOPs / that class's matrix-pipe peak) / wall "
+                                            "step time: the share of the step the matrix pipes would be busy at their peaks",
                          "algorithmic_tflops": round(tot_fl * 1e-9 / prof_steps / ms_step, 2),
                          "conv_kernel_ms_per_step": round(tot_ms / prof_steps, 3),
                          "note": "all conv / wgrad launches of a step: executed MFMA FLOPs / WALL step time (two streams overlap, so "
@@ -493,7 +503,7 @@ def main():
         if alt_modes is not None:
             out["alt_modes"] = alt_modes
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch, batch=n, decoder_channels=dec)
+            out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch, batch=n, decoder_channels=dec, precision=args.precision)
             if alt_modes is not None:
                 for mode, par in out["cpu_baseline"].pop("alt_modes_parity", {}).items():
                     alt_modes[mode]["parity_vs_cpu_ref"] = par
