@@ -121,6 +121,58 @@ hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Concat-split epilogue of a decoder conv1 dgrad (ConvArgs::out_up; the contract of conv_wino_kernel's): the output channels
+// [0, up_c0) are the gradient wrt the nearest-x2 up-sampled tensor — summed over each 2x2 pixel block, ReLU-masked by the
+// low-resolution producer, (optionally) accumulated, written at half resolution, with the fused BatchNorm-backward sums —
+// and the channels [up_c0, Cout) the gradient wrt the skip tensor, written at full resolution with its own channel count.
+// up_c0 % 64 == 0, so a 64-channel tile lies entirely on one side.  R = a [4 rows x 16 columns][kQLd] pixel block in LDS
+// (rows row0 .. row0 + nrows - 1 of it are this wave's), (hb, wb) = image coordinates of the block's pixel (0, 0).
+template <int NROWS>
+__device__ __forceinline__ void f16x3_split_epilogue(const ConvArgs& a, const float* R, int kQLd, int row0, int n, int hb, int wb, int n0, int lane,
+                                                     f4 rs, f4& ps_, f4& pq_) {
+  const int cq = lane & 15, sub = lane >> 4;
+  const int co = n0 + cq * 4;
+  if (co >= a.Cout) return;
+  if (n0 < a.up_c0) {
+    const bool bnb = a.bnb_mean != nullptr;
+    f4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = bmu, msc = {1.f, 1.f, 1.f, 1.f}, msh = bmu;
+    if (bnb) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
+    if (a.up_mscale) { msc = *(const f4*)(a.up_mscale + co); msh = *(const f4*)(a.up_mshift + co); }
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {                      // NROWS / 2 block rows x 8 block columns = NROWS * 4 blocks over 4 sub-lanes
+      const int b = r * 4 + sub;
+      const int by = b >> 3, bx = b & 7;
+      const int y = row0 + 2 * by, x = 2 * bx;
+      const int ho = hb + y, wo = wb + x;
+      if (ho < a.Ho && wo < a.Wo) {
+        const float* q = R + (y * 16 + x) * kQLd + cq * 4;
+        f4 v = (*(const f4*)q + *(const f4*)(q + kQLd) + *(const f4*)(q + 16 * kQLd) + *(const f4*)(q + 17 * kQLd)) * rs;
+        const size_t o2 = (((size_t)n * (a.Ho >> 1) + (ho >> 1)) * (a.Wo >> 1) + (wo >> 1)) * a.up_c0 + co;
+        if (a.up_mask) {
+          f4 mk = *(const f4*)(a.up_mask + o2);
+          const f4 yr = mk;
+          if (a.up_mscale) mk = mk * msc + msh;
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          if (bnb) { ps_ += v; pq_ += v * ((yr - bmu) * brs); }
+        }
+        if (a.up_accum) v += *(const f4*)(a.out_up + o2);
+        *(f4*)(a.out_up + o2) = v;
+      }
+    }
+  } else {
+    const int c1n = a.Cout - a.up_c0;
+#pragma unroll 4
+    for (int r = 0; r < NROWS * 4; ++r) {                  // NROWS * 16 pixels over 4 sub-lanes
+      const int p = r * 4 + sub;
+      const int y = row0 + (p >> 4), x = p & 15;
+      const int ho = hb + y, wo = wb + x;
+      if (ho < a.Ho && wo < a.Wo)
+        *(f4*)(a.out + (((size_t)n * a.Ho + ho) * a.Wo + wo) * c1n + (co - a.up_c0)) = *(const f4*)(R + (y * 16 + x) * kQLd + cq * 4) * rs;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- main kernel
 __device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 
@@ -302,7 +354,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   const int co = n0 + cq * 4;
   const bool cok = co < a.Cout;
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
-  {
+  const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;       // channels the statistics cover
+  if (a.out_up != nullptr) {
+    f4 rs = {0.f, 0.f, 0.f, 0.f};
+    if (cok) rs = *(const f4*)(rinv + co) * ixs;
+    f16x3_split_epilogue<4>(a, R, kQLd, 0, n, h0 + wave * 4, w0, n0, lane, rs, ps_, pq_);
+  } else {
     f4 rs = {0.f, 0.f, 0.f, 0.f}, bmu = rs, brs = rs, bia = rs, msc = {1.f, 1.f, 1.f, 1.f}, msh = rs;
     if (cok) rs = *(const f4*)(rinv + co) * ixs;
     if (bnb && cok) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
@@ -348,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     __syncthreads();
     if (tid < 64) {
       const int c1 = n0 + tid;
-      if (c1 < a.Cout) {
+      if (c1 < stat_c) {
         double sv = 0.0, qv = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { sv += (double)red[(w * 64 + tid) * 2]; qv += (double)red[(w * 64 + tid) * 2 + 1]; }
@@ -554,7 +611,12 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
   const bool cok = co < a.Cout;
   const int phalf = (wave >> 2) * 32;                      // this wave's half of the block's 64 pixels
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
-  {
+  const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;       // channels the statistics cover
+  if (a.out_up != nullptr) {
+    f4 rs = {0.f, 0.f, 0.f, 0.f};
+    if (cok) rs = *(const f4*)(rinv + co) * ixs;
+    f16x3_split_epilogue<2>(a, R, kQLd, phalf >> 4, n, h0 + mw * 4, w0, n0, lane, rs, ps_, pq_);
+  } else {
     f4 rs = {0.f, 0.f, 0.f, 0.f}, bmu = rs, brs = rs, bia = rs, msc = {1.f, 1.f, 1.f, 1.f}, msh = rs;
     if (cok) rs = *(const f4*)(rinv + co) * ixs;
     if (bnb && cok) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
@@ -599,7 +661,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
     __syncthreads();
     if (tid < 64) {
       const int c1 = n0 + tid;
-      if (c1 < a.Cout) {
+      if (c1 < stat_c) {
         double sv = 0.0, qv = 0.0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) { sv += (double)red[(w * 64 + tid) * 2]; qv += (double)red[(w * 64 + tid) * 2 + 1]; }
@@ -612,17 +674,19 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
 }
 
 // 3x3 / stride 1 / pad 1, 16-channel chunks in pairs on either side of a concat, whole 16x16 tiles not required (edges are
-// masked) but at least one; no fused concat split (ConvArgs::out_up stays on conv_wino_kernel)
+// masked) but at least one; the fused concat split (ConvArgs::out_up) with the boundary on a 64-channel tile
 bool conv_f16x3_applicable(const ConvArgs& a) {
   return a.wu != nullptr && a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && (a.rmul == 1 ? a.off == -1 : a.off == 1) &&
          (a.Ctot & 31) == 0 && (a.C0 & 15) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && (a.Cout & 3) == 0 && a.Cout >= 16 &&
-         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= 8 && a.Wo >= 16 && !a.out_up && a.Hl < 32768 && a.Wl < 32768 &&
+         a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= 8 && a.Wo >= 16 && a.Hl < 32768 && a.Wl < 32768 &&
+         (!a.out_up || (((a.Ho | a.Wo) & 1) == 0 && (a.up_c0 & 63) == 0 && a.up_c0 <= a.Cout)) &&
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
 }
 
 hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st) {
   if (!conv_f16x3_applicable(a)) return hipErrorInvalidValue;
-  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.bnb_y ? a.bnb_y : a.mask))) return hipErrorInvalidValue;
+  if (a.out_up && (a.addend || a.mask || a.bias || a.bnb_y || (a.ssum && !a.bnb_mean) || (a.up_c0 < a.Cout && !a.out))) return hipErrorInvalidValue;
+  if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum)) return hipErrorInvalidValue;
   const int tilesN = (a.Cout + 63) / 64;
   const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
   const size_t main_lds = (size_t)2 * kFBuf * sizeof(_Float16), q_lds = (size_t)4 * 64 * 68 * sizeof(float);

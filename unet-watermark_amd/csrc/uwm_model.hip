@@ -496,11 +496,11 @@ static bool f3_fwd_on(const uwm_model* m, size_t ci) {
   const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
   return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count());
 }
-// fp16x3 dgrads cover the plain epilogue only: a decoder conv1 (its dgrad splits the concat gradient in the epilogue: ConvArgs::out_up)
-// keeps the Winograd kernel
+// a decoder conv1's dgrad splits the concat gradient in its epilogue (ConvArgs::out_up): the fp16x3 kernel takes it when the
+// boundary sits on a 64-channel tile
 static bool f3d_plain(const uwm_model* m, int ci) {
-  for (auto& d : m->dec) if (d.c1 == ci) return false;
-  for (auto& nd : m->nodes) if (nd.c1 == ci) return false;
+  for (auto& d : m->dec) if (d.c1 == ci) return (d.C0 & 63) == 0;
+  for (auto& nd : m->nodes) if (nd.c1 == ci) return (nd.C0 & 63) == 0;
   return true;
 }
 // fp16x3 weight gradient: rows of whole 32-pixel k-steps, 4-row stages, 32-channel tiles on either side of the concat; at most 256
@@ -590,7 +590,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
     a.wu = c.F(cv.wud_off); a.wu_ncb = wino_ncb(cv.CinP);
     const int pm = c.m->plan.prec;
     if ((pm == UWM_PREC_BF16X3 || pm == UWM_PREC_BF16X3_ALL) && cv.x3_d()) a.prec = 1;
-    if (f3_dgrad_on(c.m, (size_t)ci) && !us) {        // fp16x3 direct form: dY scaled by the power of two bn_bwd_apply's max|dy| calls for
+    if (f3_dgrad_on(c.m, (size_t)ci) && (!us || (us->C0 & 63) == 0)) {        // fp16x3 direct form: dY scaled by the power of two bn_bwd_apply's max|dy| calls for
       a.prec = 2; a.wu_ncb = f16x3_nj(cv.CinP); a.wu_rinv_off = (int)f16x3_rinv_off(cv.CinP, cv.CoutP);
       a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off());
     }
@@ -1213,6 +1213,7 @@ int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
     for (int i = 0; i < 5; ++i) if (!strcmp(pe, names[i]) || (pe[0] == '0' + i && !pe[1])) m->prec = i;
     m->plan.prec = m->prec;
   }
+  if (const char* pf = getenv("UWM_F16X3_MIN_WGS")) m->f3_min_wgs = atoi(pf) > 0 ? atoi(pf) : 0;      // process default of uwm_set_precision_fill
   m->wino_mode = winograd_mode();       // process default (UWM_WINOGRAD / uwm_set_winograd) at creation; then per handle
   m->plan.wino_mode = m->wino_mode;
   *out = m; return 0;
