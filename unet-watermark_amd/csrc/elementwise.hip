@@ -300,12 +300,12 @@ hipError_t launch_bn_bwd_reduce(const float* g, const float* y, const float* mea
 // (run_dgrad bn_fuse); the workgroup adds them up itself for the channels it touches, in a fixed order (bit-reproducible, the
 // same value in every workgroup) — the separate bn_bwd_fold launch between every dgrad and its apply pass (42 per resnet34
 // step, each queued behind the other stream's workgroups: 1.2 ms of critical-path latency) is gone.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
+__global__ __launch_bounds__(256, 6) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                     const double* __restrict__ dgamma, const double* __restrict__ dbeta, float* __restrict__ dy,
                                     float* gamma_grad, float* beta_grad, size_t n4, int C, float invM,
                                     const double* __restrict__ rep, int nrep, int rep_stride, float* xmax) {
-  __shared__ double part[256 * 8];
+  __shared__ double part[256 * 4];
   __shared__ float wmax[4];
   float amax = 0.f;                                  // max |dy| of this thread's outputs (xmax != nullptr)
   // dy = gm*rs*(g - db - (y-mu)*rs*dg) = A*g + B*y + K per channel; the grid stride is a multiple of C/4, so a thread
@@ -322,59 +322,71 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     y0 = *(const f4*)(y + i * 4); y1 = *(const f4*)(y + (i + stride) * 4); y2 = *(const f4*)(y + (i + 2 * stride) * 4); y3 = *(const f4*)(y + (i + 3 * stride) * 4);
   }
   const f4 mu = *(const f4*)(mean + c), rs = *(const f4*)(rstd + c), gm = *(const f4*)(gamma + c);
-  double sdb[4], sdg[4];
-  if (rep) {
-    // the workgroup touches quads (q0 + t) % Q, t < 256: nq distinct ones; L replica lanes per quad share the nrep copies
-    const int nq = Q < 256 ? Q : 256, L = 256 / nq;
-    const int q0 = (int)(((size_t)blockIdx.x * 256) % (size_t)Q);
-    const int j = threadIdx.x % nq, l = threadIdx.x / nq;
-    if (l < L) {
-      const int cj = ((q0 + j) % Q) * 4;
-      double b0 = 0, b1 = 0, b2 = 0, b3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-      for (int r = l; r < nrep; r += L) {
-        const double* pr = rep + (size_t)r * rep_stride + cj;
-        b0 += pr[0]; b1 += pr[1]; b2 += pr[2]; b3 += pr[3];
-        d0 += pr[C]; d1 += pr[C + 1]; d2 += pr[C + 2]; d3 += pr[C + 3];
+  // folded sums: dbeta quad, then dgamma quad (one after the other: 8 instead of 16 fp64 accumulators live at a time — the
+  // kernel has to stay under 80 VGPRs, see the loop below)
+  f4 dbq, dgq;                                         // sums as floats scaled by 1 / M
+  {
+    double sq[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (rep) {
+        // the workgroup touches quads (q0 + t) % Q, t < 256: nq distinct ones; L replica lanes per quad share the nrep copies
+        const int nq = Q < 256 ? Q : 256, L = 256 / nq;
+        const int q0 = (int)(((size_t)blockIdx.x * 256) % (size_t)Q);
+        const int j = threadIdx.x % nq, l = threadIdx.x / nq;
+        if (half) __syncthreads();
+        if (l < L) {
+          const int cj = ((q0 + j) % Q) * 4 + half * C;
+          double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+          for (int r = l; r < nrep; r += L) {
+            const double* pr = rep + (size_t)r * rep_stride + cj;
+            b0 += pr[0]; b1 += pr[1]; b2 += pr[2]; b3 += pr[3];
+          }
+          double* o = part + (l * nq + j) * 4;
+          o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq[e] = 0.0;
+        for (int k = 0; k < L; ++k) {                  // fixed order over the replica lanes
+          const double* o = part + (k * nq + j) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq[e] += o[e];
+        }
+      } else {
+        const double* src = half ? dgamma : dbeta;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sq[e] = src[c + e];
       }
-      double* o = part + (l * nq + j) * 8;
-      o[0] = b0; o[1] = b1; o[2] = b2; o[3] = b3; o[4] = d0; o[5] = d1; o[6] = d2; o[7] = d3;
+      float* gout = half ? gamma_grad : beta_grad;
+      if (gout && i < (size_t)Q) {                     // the first Q threads of the grid hold every channel quad once
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gout[c + e] = (float)sq[e];
+      }
+      f4 q4; q4.x = (float)sq[0] * invM; q4.y = (float)sq[1] * invM; q4.z = (float)sq[2] * invM; q4.w = (float)sq[3] * invM;
+      if (half) dgq = q4; else dbq = q4;
     }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { sdb[e] = 0.0; sdg[e] = 0.0; }
-    for (int k = 0; k < L; ++k) {                    // fixed order over the replica lanes
-      const double* o = part + (k * nq + j) * 8;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { sdb[e] += o[e]; sdg[e] += o[4 + e]; }
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { sdb[e] = dbeta[c + e]; sdg[e] = dgamma[c + e]; }
-  }
-  if (gamma_grad && i < (size_t)Q) {                   // the first Q threads of the grid hold every channel quad once
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { gamma_grad[c + e] = (float)sdg[e]; beta_grad[c + e] = (float)sdb[e]; }
   }
   if (i >= n4 && !xmax) return;
-  f4 dg, db;
-  dg.x = (float)sdg[0] * invM; dg.y = (float)sdg[1] * invM; dg.z = (float)sdg[2] * invM; dg.w = (float)sdg[3] * invM;
-  db.x = (float)sdb[0] * invM; db.y = (float)sdb[1] * invM; db.z = (float)sdb[2] * invM; db.w = (float)sdb[3] * invM;
+  const f4 dg = dgq, db = dbq;
   const f4 A = gm * rs, B = -(gm * rs * rs * dg), K = -(A * db) - B * mu;
   auto amax4 = [&](const f4& v) { amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  // (no software prefetch across iterations: the kernel is kept under 80 VGPRs so that its workgroups fit beside the 768-thread
+  // weight-gradient workgroups of the other stream — 3 x 144 of a SIMD's 512 registers — instead of waiting for one to retire:
+  // 89.6 us per launch in the step against 29.8 alone before)
   while (full) {
-    const f4 o0 = A * g0 + B * y0 + K, o1 = A * g1 + B * y1 + K, o2 = A * g2 + B * y2 + K, o3 = A * g3 + B * y3 + K;
-    if (xmax) { amax4(o0); amax4(o1); amax4(o2); amax4(o3); }
-    const size_t io = i;
+    g0 = A * g0 + B * y0 + K; g1 = A * g1 + B * y1 + K; g2 = A * g2 + B * y2 + K; g3 = A * g3 + B * y3 + K;
+    if (xmax) { amax4(g0); amax4(g1); amax4(g2); amax4(g3); }
+    *(f4*)(dy + i * 4) = g0;
+    *(f4*)(dy + (i + stride) * 4) = g1;
+    *(f4*)(dy + (i + 2 * stride) * 4) = g2;
+    *(f4*)(dy + (i + 3 * stride) * 4) = g3;
     i += 4 * stride;
     full = i + 3 * stride < n4;
-    if (full) {                                        // next iteration's loads before this one's stores
+    if (full) {
       g0 = *(const f4*)(g + i * 4); g1 = *(const f4*)(g + (i + stride) * 4); g2 = *(const f4*)(g + (i + 2 * stride) * 4); g3 = *(const f4*)(g + (i + 3 * stride) * 4);
       y0 = *(const f4*)(y + i * 4); y1 = *(const f4*)(y + (i + stride) * 4); y2 = *(const f4*)(y + (i + 2 * stride) * 4); y3 = *(const f4*)(y + (i + 3 * stride) * 4);
     }
-    *(f4*)(dy + io * 4) = o0;
-    *(f4*)(dy + (io + stride) * 4) = o1;
-    *(f4*)(dy + (io + 2 * stride) * 4) = o2;
-    *(f4*)(dy + (io + 3 * stride) * 4) = o3;
   }
   for (; i < n4; i += stride) {
     const f4 o = A * *(const f4*)(g + i * 4) + B * *(const f4*)(y + i * 4) + K;
