@@ -63,23 +63,55 @@ __device__ __forceinline__ float f16x3_wval(const WinoJob& jb, int row, int slot
   if (jb.mode == 0) return jb.w[(size_t)row * jb.Kpad + (size_t)slot * jb.chans + ch];
   return ch < jb.src_rows ? jb.w[(size_t)ch * jb.Kpad + (size_t)(8 - slot) * jb.rows + row] : 0.f;
 }
-// one wave per filter row: s = 2^(14 - e) for row max = m * 2^e (m in [0.5, 1)): the largest tap lands in [2^13, 2^14)
+// Row maxima -> row scales, two launches: (1) max|w| per filter row into rmax (zeroed; non-negative floats order as integers, so the
+// partial maxima of the workgroups that share a row meet in an atomicMax), with lanes along whatever is contiguous in memory —
+// the k index of a forward bank (a wave per row, 4 rows per workgroup, the k range split over blockIdx.z), the ROW index of a
+// dgrad bank built from the forward weights (mode 2: a lane per row, 64 rows per wave, (tap, channel) split over waves and
+// blockIdx.z); (2) rinv[row] = 2^(e - 14) for row max = m * 2^e (m in [0.5, 1)): the largest tap lands in [2^13, 2^14).
+// (The first version — one wave per row walking the whole row — took 70-94 us per launch, 0.19 ms per step.)
+__global__ __launch_bounds__(256) void f16x3_rowzero_kernel(const WinoJobs jobs) {
+  const WinoJob jb = jobs.j[blockIdx.y];
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row < f16x3_nj_(jb.rows) * 16) (jb.ut + f16x3_rinv_off_floats(jb.rows, jb.chans))[row] = 0.f;
+}
+__global__ __launch_bounds__(256) void f16x3_rowmax_kernel(const WinoJobs jobs) {
+  const WinoJob jb = jobs.j[blockIdx.y];
+  const int nJ = f16x3_nj_(jb.rows);
+  unsigned* rmax = (unsigned*)(jb.ut + f16x3_rinv_off_floats(jb.rows, jb.chans));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int K = 9 * jb.chans, nz = gridDim.z, z = blockIdx.z;
+  if (jb.mode == 0) {
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= jb.rows) return;
+    float mx = 0.f;
+    const float* wr = jb.w + (size_t)row * jb.Kpad;
+    for (int i = z * 64 + lane; i < K; i += nz * 64) mx = fmaxf(mx, fabsf(wr[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (lane == 0 && mx > 0.f) atomicMax(rmax + row, __float_as_uint(mx));
+  } else {
+    const int row = blockIdx.x * 64 + lane;            // (blockIdx.x counts 64-row groups here)
+    if (blockIdx.x * 64 >= jb.rows) return;
+    float mx = 0.f;
+    if (row < jb.rows)
+      for (int i = z * 4 + wv; i < 9 * jb.src_rows; i += nz * 4) {      // i = ch * 9 + tap
+        const int ch = i / 9, tap = i - ch * 9;
+        mx = fmaxf(mx, fabsf(jb.w[(size_t)ch * jb.Kpad + (size_t)tap * jb.rows + row]));
+      }
+    if (row < jb.rows && mx > 0.f) atomicMax(rmax + row, __float_as_uint(mx));
+  }
+  (void)nJ;
+}
 __global__ __launch_bounds__(256) void f16x3_rowscale_kernel(const WinoJobs jobs) {
   const WinoJob jb = jobs.j[blockIdx.y];
   const int nJ = f16x3_nj_(jb.rows);
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= nJ * 16) return;
-  float mx = 0.f;
-  if (row < jb.rows)
-    for (int i = lane; i < 9 * jb.chans; i += 64) mx = fmaxf(mx, fabsf(f16x3_wval(jb, row, i / jb.chans, i % jb.chans)));
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-  if (lane == 0) {
-    float s = 1.f;
-    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); s = ldexpf(1.f, 14 - e); }
-    float* rinv = jb.ut + f16x3_rinv_off_floats(jb.rows, jb.chans);
-    rinv[row] = 1.f / s;                             // (exact: a power of two)
-  }
+  float* rinv = jb.ut + f16x3_rinv_off_floats(jb.rows, jb.chans);
+  const float mx = rinv[row];                          // (the maximum, left there by f16x3_rowmax_kernel; 0 for padding rows)
+  float s = 1.f;
+  if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); s = ldexpf(1.f, 14 - e); }
+  rinv[row] = 1.f / s;                                 // (exact: a power of two)
 }
 __global__ __launch_bounds__(256) void f16x3_weights_multi_kernel(const WinoJobs jobs) {
   const WinoJob jb = jobs.j[blockIdx.y];
@@ -116,7 +148,9 @@ hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st) {
     if (t > mx) mx = t;
     if (f16x3_nj(jobs.j[i].rows) * 16 > mr) mr = f16x3_nj(jobs.j[i].rows) * 16;
   }
-  hipLaunchKernelGGL(f16x3_rowscale_kernel, dim3((unsigned)((mr + 3) / 4), (unsigned)jobs.n), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(f16x3_rowzero_kernel, dim3((unsigned)((mr + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);      // the row maxima meet in atomicMax: start from zero
+  hipLaunchKernelGGL(f16x3_rowmax_kernel, dim3((unsigned)((mr + 3) / 4), (unsigned)jobs.n, 8), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(f16x3_rowscale_kernel, dim3((unsigned)((mr + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);
   hipLaunchKernelGGL(f16x3_weights_multi_kernel, dim3((unsigned)((mx + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);
   return hipGetLastError();
 }
