@@ -12,12 +12,14 @@ def main():
     ap.add_argument("--batch", type=int, default=64); ap.add_argument("--batches", type=int, default=64)
     ap.add_argument("--size", type=int, default=512); ap.add_argument("--encoder", default="resnet34")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="f16x3 (default): fp16x3 split products on the 3x3 convolutions, fp32-class accuracy; f32: exact-fp32 matrix instruction")
     a = ap.parse_args()
     from unet_watermark_amd.predict import WatermarkPredictor
     from unet_watermark_amd.config import get_cfg_defaults
     cfg = get_cfg_defaults(); cfg.MODEL.NAME = "Unet"; cfg.MODEL.ENCODER_NAME = a.encoder      # BASELINE configs[4] names Unet
     torch.manual_seed(42)
-    pred = WatermarkPredictor(config=cfg, device="cuda")
+    pred = WatermarkPredictor(config=cfg, device="cuda", precision=a.precision)
     x = torch.randn(a.batch, 3, a.size, a.size, device="cuda")
     for _ in range(2):
         m = pred.predict_mask(x, use_graph=not a.no_graph)
@@ -35,7 +37,9 @@ def main():
     for i in (0, a.batch // 2, a.batch - 1):
         eq = eq and bool(torch.equal(pred.logits(x[i:i + 1], use_graph=False)[0], lb[i]))
     print(json.dumps({"metric": "predict_images_per_sec", "value": round(n / dt, 2), "unit": "images/s", "n_gpus": 1,
-                      "images": n, "batch": a.batch, "ms_per_batch": round(1e3 * dt / a.batches, 3), "dtype": "f32",
+                      "images": n, "batch": a.batch, "ms_per_batch": round(1e3 * dt / a.batches, 3),
+                      "dtype": "f32" if a.precision == "f32" else "f32 storage / accumulation, 3x3 conv products as fp16x3 splits (22-bit operands) on v_mfma_f32_16x16x32_f16",
+                      "precision_mode": a.precision,
                       "data": "synthetic", "hipgraph": not a.no_graph,
                       "config": {"workload": f"Unet-{a.encoder} {a.size}x{a.size} eval forward + logit threshold, bs{a.batch} (BASELINE configs[4])"},
                       "model_tflops": round(n * fwd / dt / 1e12, 2), "mask_positive_frac": round(float((m > 0).float().mean()), 4),

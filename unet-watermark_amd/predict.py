@@ -20,7 +20,7 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 
 class WatermarkPredictor:
     def __init__(self, model_path: Optional[str] = None, config_path: Optional[str] = None, config=None,
-                 device: str = "cuda", model=None):
+                 device: str = "cuda", model=None, precision: Optional[str] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("WatermarkPredictor runs only on a HIP device (no CPU fallback)")
@@ -31,6 +31,10 @@ class WatermarkPredictor:
         if model_path:
             load_checkpoint(model_path, self.model)
         self.model.to(self.device).eval()
+        if precision is not None:
+            # "f16x3": the 3x3 convolutions on the fp16x3 kernels (fp32-class accuracy).  The fill threshold is dropped to 1 so that
+            # the kernel choice does not depend on the batch size: an image's logits stay bit-identical whatever batch it rides in
+            self.model.set_precision(precision, min_workgroups=1 if precision.startswith("f16x3") else None)
         self.threshold = float(self.cfg.PREDICT.THRESHOLD)
         self._graph = None
         self._gkey = None
