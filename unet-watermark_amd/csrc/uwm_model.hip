@@ -503,12 +503,10 @@ static bool f3d_plain(const uwm_model* m, int ci) {
   for (auto& nd : m->nodes) if (nd.c1 == ci) return (nd.C0 & 63) == 0;
   return true;
 }
-// fp16x3 weight gradient: rows of whole 32-pixel k-steps, 4-row stages, 32-channel tiles on either side of the concat; at most 256
-// input channels (a workgroup owns 64 x 32 channels of dW: wider layers re-read dY once per 32 input channels and the
-// Winograd-domain kernel stays ahead: 296 vs 320 us on 384 -> 128 at 64^2, profiles/r03_*_time_wgrad_f16x3.txt)
+// fp16x3 weight gradient: rows of whole 32-pixel k-steps, 4-row stages, 32-channel tiles on either side of the concat
 static bool f3_wgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
-  return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP && cv.CinP <= 256 &&
+  return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP &&
          (p.ow[ci] % 32) == 0 && (p.oh[ci] % 4) == 0 && p.ow[ci] >= 32 && !dbg_flag("UWM_NO_F16X3_WGRAD");
 }
 static bool f3_dgrad_on(const uwm_model* m, size_t ci) {

@@ -96,28 +96,41 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
     if (xhas) { xsc = *(const f4*)(s.scale + cl + xcu * 4); xsh = *(const f4*)(s.shift + cl + xcu * 4); }
     const int xrelu = s.relu;
     struct Stage { f4 dv[kWDyRounds]; f4 xv[kWXRounds]; unsigned xok; };
+    // stage-invariant pieces of the unit addresses (the loaders are the critical role: every integer operation taken out of
+    // stage_load / stage_store counts): dY pixel offsets and LDS positions, X patch coordinates and LDS positions
+    int dgo[kWDyRounds], dlo[kWDyRounds], xpy[kWXRounds], xlo[kWXRounds];
+#pragma unroll
+    for (int rd = 0; rd < kWDyRounds; ++rd) {
+      const int px = (rd * kWLT + ltid) >> 4;
+      dgo[rd] = ((px >> 5) * a.Wo + (px & 31)) * a.Cout;
+      dlo[rd] = off_dy(px, dcu >> 1) + (dcu & 1) * 8;
+    }
+#pragma unroll
+    for (int rd = 0; rd < kWXRounds; ++rd) {
+      const int pp = (rd * kWLT + ltid) >> 3;
+      const bool act = pp < kWPH * kWPW;
+      const int py = act ? pp / kWPW : 0, px = act ? pp - py * kWPW : 0;
+      xpy[rd] = act ? ((py << 8) | px) : -1;
+      xlo[rd] = pp * kWXS + xcu * 8;
+    }
+    const float* const dyp = a.dy + a0 + dcu * 4;
+    const float* const xp = s.ptr + cl + xcu * 4;
     auto stage_load = [&](int st, Stage& sg) {
       int q = st;
       const int tx = q % tilesX; q /= tilesX;
       const int ty = q % tilesY; const int n = q / tilesY;
       const int y0 = ty * kWR, x0 = tx * kWX;
+      const float* const dbase = dyp + (((size_t)n * a.Ho + y0) * a.Wo + x0) * a.Cout;
 #pragma unroll
-      for (int rd = 0; rd < kWDyRounds; ++rd) {
-        const int px = (rd * kWLT + ltid) >> 4;
-        const size_t o = (((size_t)n * a.Ho + y0 + (px >> 5)) * a.Wo + x0 + (px & 31)) * a.Cout + a0 + dcu * 4;
-        sg.dv[rd] = dok ? *(const f4*)(a.dy + o) : (f4){0.f, 0.f, 0.f, 0.f};
-      }
+      for (int rd = 0; rd < kWDyRounds; ++rd) sg.dv[rd] = dok ? *(const f4*)(dbase + dgo[rd]) : (f4){0.f, 0.f, 0.f, 0.f};
       sg.xok = 0;
+      const int nb = n * s.H;
 #pragma unroll
       for (int rd = 0; rd < kWXRounds; ++rd) {
-        const int pp = (rd * kWLT + ltid) >> 3;
-        const bool act = pp < kWPH * kWPW;
-        const int py = act ? pp / kWPW : 0, px = act ? pp - py * kWPW : 0;
-        const int hl = y0 - 1 + py, wl = x0 - 1 + px;
-        const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+        const int hl = y0 - 1 + (xpy[rd] >> 8), wl = x0 - 1 + (xpy[rd] & 255);
+        const bool ok = xpy[rd] >= 0 && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
         const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
-        const size_t o = (((size_t)n * s.H + (hc >> s.up)) * s.W + (wc >> s.up)) * s.C + cl + xcu * 4;
-        sg.xv[rd] = *(const f4*)(s.ptr + o);
+        sg.xv[rd] = *(const f4*)(xp + (size_t)(((nb + (hc >> s.up)) * s.W + (wc >> s.up))) * s.C);
         sg.xok |= (ok ? 1u : 0u) << rd;
       }
     };
@@ -135,23 +148,17 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
       char* const dyb = wsm + buf * kWStage;
       char* const xb = dyb + kWDyB;
 #pragma unroll
-      for (int rd = 0; rd < kWDyRounds; ++rd) {
-        const int px = (rd * kWLT + ltid) >> 4;
-        const int o = off_dy(px, dcu >> 1) + (dcu & 1) * 8;
-        split_store(dyb + o, dyb + (o ^ 128), sg.dv[rd] * xs);        // lo plane: chunk + 8 (bit 3 of the swizzled chunk index)
-      }
+      for (int rd = 0; rd < kWDyRounds; ++rd) split_store(dyb + dlo[rd], dyb + (dlo[rd] ^ 128), sg.dv[rd] * xs);      // lo plane: chunk + 8 (bit 7 of the swizzled offset)
 #pragma unroll
       for (int rd = 0; rd < kWXRounds; ++rd) {
-        const int pp = (rd * kWLT + ltid) >> 3;
-        if (pp < kWPH * kWPW) {
+        if (xpy[rd] >= 0) {
           f4 v = sg.xv[rd];
           if (xhas) {
             v = v * xsc + xsh;
             if (xrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           }
           if (!((sg.xok >> rd) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
-          char* d = xb + pp * kWXS + xcu * 8;
-          split_store(d, d + 64, v);
+          split_store(xb + xlo[rd], xb + xlo[rd] + 64, v);
         }
       }
     };
@@ -255,7 +262,8 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
 bool wgrad_f16x3_applicable(const WgradArgs& a) {
   return a.xmax != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
          (a.Cout & 3) == 0 && a.wrows <= a.Cout && a.Kpad == 9 * a.Ctot && a.Hl == a.Ho && a.Wl == a.Wo &&
-         (a.Wo % kWX) == 0 && (a.Ho % kWR) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0;
+         (a.Wo % kWX) == 0 && (a.Ho % kWR) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && a.Wo < 256 * 128 &&
+         (size_t)a.N * a.s0.H * a.s0.W < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W < (1ull << 31) && (size_t)kWR * a.Wo * a.Cout < (1ull << 31);
 }
 
 hipError_t launch_wgrad_f16x3(const WgradArgs& a0, hipStream_t st) {
