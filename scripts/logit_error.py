@@ -1,5 +1,5 @@
 """Logit max-abs error of the HIP path against the fp32 CPU oracle and an fp64 run of it (train- and eval-mode
-BatchNorm), with Winograd on and off.  Needs an MI355X.  usage: logit_error.py [encoder] [N] [H] [W]"""
+BatchNorm), with Winograd on and off and in the split-precision forward modes (fp16x3, bf16x3).  Needs an MI355X.  usage: logit_error.py [encoder] [N] [H] [W]"""
 import sys, os, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,10 +19,11 @@ for mode in ("eval", "train"):      # eval first: the train-mode forwards update
     getattr(ref, mode)(); getattr(ref64, mode)(); getattr(m, mode)()
     with torch.no_grad():
         o32 = ref(x); o64 = ref64(x.double())
-    for wino in (1, 0):
+    for wino, prec in ((1, "f32"), (0, "f32"), (1, "f16x3"), (1, "bf16x3_all")):
         L.check(L.lib().uwm_set_winograd_mode(m._h, wino))
+        m.set_precision(prec, min_workgroups=1)             # fill threshold 1: every eligible layer on the split-product kernels
         with torch.no_grad():
             o = m(x.to(dev)).cpu()
-        print(f"{enc} {n}x{h}x{w} {mode:5s} winograd={wino}: |hip-oracle32| {float((o - o32).abs().max()):.2e}  "
+        print(f"{enc} {n}x{h}x{w} {mode:5s} winograd={wino} precision={prec:10s}: |hip-oracle32| {float((o - o32).abs().max()):.2e}  "
               f"|hip-oracle64| {float((o.double() - o64).abs().max()):.2e}  |oracle32-oracle64| {float((o32.double() - o64).abs().max()):.2e}  "
               f"logit range {float(o32.abs().max()):.2f}")
