@@ -816,6 +816,8 @@ def test_conv_f16x3_upsample_concat(cuda):
     (2, 64, 64, 16, 32, 1.0),        # layer1-like: one output-channel tile, two input-channel tiles
     (1, 32, 128, 8, 64, 1e-6),       # two output-channel tiles; dY as tiny as a real Dice gradient (scaled through xmax)
     (3, 96, 80, 12, 32, 1e-3),       # Cout 80 over-hangs the 64-channel tile; odd stage counts per split
+    (4, 64, 128, 16, 16, 1e-5),      # 16-pixel-wide map (layer4-like): 8 x 16-pixel stages, two image rows per k-step
+    (2, 32, 64, 8, 48, 1e-2),        # width 48: not a multiple of 32, three 16-pixel stage columns
 ])
 def test_wgrad_f16x3_direct(cuda, case):
     """wgrad_f16x3.hip (force 6): direct 3x3 weight gradient on v_mfma_f32_16x16x32_f16, pixels as the MFMA K dimension

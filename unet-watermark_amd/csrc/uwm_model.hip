@@ -503,11 +503,11 @@ static bool f3d_plain(const uwm_model* m, int ci) {
   for (auto& nd : m->nodes) if (nd.c1 == ci) return (nd.C0 & 63) == 0;
   return true;
 }
-// fp16x3 weight gradient: rows of whole 32-pixel k-steps, 4-row stages, 32-channel tiles on either side of the concat
+// fp16x3 weight gradient: the map tiled by whole 4 x 32- or 8 x 16-pixel stages, 32-channel tiles on either side of the concat
 static bool f3_wgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP &&
-         (p.ow[ci] % 32) == 0 && (p.oh[ci] % 4) == 0 && p.ow[ci] >= 32 && !dbg_flag("UWM_NO_F16X3_WGRAD");
+         (((p.ow[ci] % 32) == 0 && (p.oh[ci] % 4) == 0) || ((p.ow[ci] % 16) == 0 && (p.oh[ci] % 8) == 0)) && !dbg_flag("UWM_NO_F16X3_WGRAD");
 }
 static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;

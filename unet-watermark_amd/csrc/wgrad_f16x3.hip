@@ -34,14 +34,18 @@ typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 #ifndef UWM_WG16_ABL
 #define UWM_WG16_ABL 0      // compile-time timing ablations (scripts/ablate_f16x3.sh wgrad ...): 1 no MFMA, 2 no X fragment reads, 4 no loader work after the first stage; 0 in the product build
 #endif
-constexpr int kWR = 4, kWX = 32, kWPW = kWX + 2, kWPH = kWR + 2;      // stage = 4 rows x 32 pixels; halo patch 6 x 34
-constexpr int kWDyB = kWR * kWX * 256;                                // bytes of a dY stage image (32 768)
+// Stage geometry: 128 pixels = kWR rows x WX pixels (WX = 32: 4 x 32, one image row per 32-pixel k-step; WX = 16, the 16-pixel-wide
+// maps of the deepest encoder stage: 8 x 16, two image rows per k-step).  Halo patch (kWR + 2) x (WX + 2).
+template <int WX> struct WG16 {
+  static constexpr int kWR = 128 / WX, kWX = WX, kWPW = WX + 2, kWPH = kWR + 2;
+  static constexpr int kWXB = kWPH * kWPW * 136;                         // bytes of an X stage image (27 744 / 24 480)
+  static constexpr int kWStage = 32768 + ((kWXB + 255) & ~255);          // bytes per stage buffer
+  static constexpr int kWXRounds = (kWPH * kWPW * 8 + 511) / 512;        // X units per loader thread: 4 / 3
+};
+constexpr int kWDyB = 128 * 256;                                       // bytes of a dY stage image (32 768)
 constexpr int kWXS = 136;                                              // bytes per X patch pixel (128 + 8 pad)
-constexpr int kWXB = kWPH * kWPW * kWXS;                               // bytes of an X stage image (27 744)
-constexpr int kWStage = kWDyB + ((kWXB + 255) & ~255);                 // bytes per stage buffer
 constexpr int kWLT = 512;                                              // loader threads (8 waves) next to the 4 MMA waves
-constexpr int kWDyRounds = kWR * kWX * 16 / kWLT;                      // dY 16-byte units per loader thread: 4
-constexpr int kWXRounds = (kWPH * kWPW * 8 + kWLT - 1) / kWLT;         // X units per loader thread: 4
+constexpr int kWDyRounds = 128 * 16 / kWLT;                            // dY 16-byte units per loader thread: 4
 
 __device__ __forceinline__ int off_dy(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 __device__ __forceinline__ float clamp_hw(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
@@ -53,7 +57,10 @@ __device__ __forceinline__ h8 tr_pair(const char* base, int o0, int o1) {      /
   return __builtin_bit_cast(h8, v);
 }
 
+template <int WX>
 __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, int stages_per_split, int nstages) {
+  constexpr int kWR = WG16<WX>::kWR, kWX = WX, kWPW = WG16<WX>::kWPW, kWPH = WG16<WX>::kWPH, kWStage = WG16<WX>::kWStage, kWXRounds = WG16<WX>::kWXRounds;
+  constexpr int kKS = 4, kRK = 32 / WX;                // k-steps (32 pixels) per stage; image rows per k-step (1 / 2)
   extern __shared__ __attribute__((aligned(256))) char wsm[];       // [2][dY image | X image]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_mma = wave < 4;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
 #pragma unroll
     for (int rd = 0; rd < kWDyRounds; ++rd) {
       const int px = (rd * kWLT + ltid) >> 4;
-      dgo[rd] = ((px >> 5) * a.Wo + (px & 31)) * a.Cout;
+      dgo[rd] = ((px / kWX) * a.Wo + (px % kWX)) * a.Cout;
       dlo[rd] = off_dy(px, dcu >> 1) + (dcu & 1) * 8;
     }
 #pragma unroll
@@ -194,20 +201,20 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
 #pragma unroll
       for (int rdx = 0; rdx < 2; ++rdx)
         dyo[cf][rdx] = off_dy(8 * kg + 4 * rdx + q, 2 * (2 * cp + cf) + (p >> 1)) + 8 * (p & 1);
-    // X fragment base (bytes inside an X image): patch pixel (row 0, column 8*kg + q), chunk 2*bf + (p>>1)
-    const int xo = (8 * kg + q) * kWXS + (2 * bf + (p >> 1)) * 16 + 8 * (p & 1);
+    // X fragment base (bytes inside an X image): patch pixel of k index 8*kg + q of k-step 0 (row (8kg) / WX, column (8kg) % WX + q), chunk 2*bf + (p>>1)
+    const int xo = (((8 * kg) / kWX) * kWPW + (8 * kg) % kWX + q) * kWXS + (2 * bf + (p >> 1)) * 16 + 8 * (p & 1);
     const int ns = st1 - st0;
     __syncthreads();
     for (int i = 0; i < ns; ++i) {
       const char* const dyb = wsm + (i & 1) * kWStage;
       const char* const xb = dyb + kWDyB;
 #pragma unroll
-      for (int kr = 0; kr < kWR; ++kr) {
+      for (int kr = 0; kr < kKS; ++kr) {
         h8 ah[2], al[2];
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
-          ah[cf] = tr_pair(dyb + kr * kWX * 256, dyo[cf][0], dyo[cf][1]);
-          al[cf] = tr_pair(dyb + kr * kWX * 256, dyo[cf][0] ^ 128, dyo[cf][1] ^ 128);
+          ah[cf] = tr_pair(dyb + kr * 32 * 256, dyo[cf][0], dyo[cf][1]);
+          al[cf] = tr_pair(dyb + kr * 32 * 256, dyo[cf][0] ^ 128, dyo[cf][1] ^ 128);
         }
         // Iteration it: the X fragments of tap it+1 are read (one tap ahead of their first use), hh of tap it and hl, lh of tap
         // it-1 are issued, interleaved over the two channel fragments so that the three products of a tile — they update the SAME
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
         h8 xh[3], xl[3];
         auto x_read = [&](int t) {
           const int r = t / 3, sx = t % 3;
-          const char* xp = xb + ((kr + r) * kWPW + sx) * kWXS + xo;
+          const char* xp = xb + ((kr * kRK + r) * kWPW + sx) * kWXS + xo;
           xh[t % 3] = (UWM_WG16_ABL & 2) ? ah[0] : tr_pair(xp, 0, 4 * kWXS);
           xl[t % 3] = (UWM_WG16_ABL & 2) ? al[1] : tr_pair(xp, 64, 4 * kWXS + 64);
         };
@@ -257,21 +264,36 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
   }
 }
 
-// 3x3 / stride 1 / pad 1, input channels in whole 32-channel tiles on either side of the concat, image rows of whole 32-pixel
-// k-steps and 4-row stages, dY scaled through a.xmax
+// 3x3 / stride 1 / pad 1, input channels in whole 32-channel tiles on either side of the concat, the image tiled by whole
+// 4 x 32-pixel or 8 x 16-pixel stages, dY scaled through a.xmax
+static int wgrad_f16x3_wx(const WgradArgs& a) {
+  if ((a.Wo % 32) == 0 && (a.Ho % 4) == 0) return 32;
+  if ((a.Wo % 16) == 0 && (a.Ho % 8) == 0) return 16;
+  return 0;
+}
 bool wgrad_f16x3_applicable(const WgradArgs& a) {
   return a.xmax != nullptr && a.ntaps == 9 && a.kw == 3 && a.stride == 1 && a.pad == 1 && (a.Ctot & 31) == 0 && (a.C0 & 31) == 0 &&
          (a.Cout & 3) == 0 && a.wrows <= a.Cout && a.Kpad == 9 * a.Ctot && a.Hl == a.Ho && a.Wl == a.Wo &&
-         (a.Wo % kWX) == 0 && (a.Ho % kWR) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && a.Wo < 256 * 128 &&
-         (size_t)a.N * a.s0.H * a.s0.W < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W < (1ull << 31) && (size_t)kWR * a.Wo * a.Cout < (1ull << 31);
+         wgrad_f16x3_wx(a) != 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && a.Wo < 256 * 128 &&
+         (size_t)a.N * a.s0.H * a.s0.W < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W < (1ull << 31) && (size_t)8 * a.Wo * a.Cout < (1ull << 31);
+}
+
+template <int WX>
+static hipError_t launch_wg16(WgradArgs& a, hipStream_t st, int pairs, int sps, int nstages) {
+  const size_t lds = (size_t)2 * WG16<WX>::kWStage;
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_f16x3_kernel<WX>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(43, a.flops, a.bytes, (wgrad_f16x3_kernel<WX>), dim3((unsigned)(pairs * a.nsplit)), dim3(768), lds, st, a, sps, nstages);
+  return hipGetLastError();
 }
 
 hipError_t launch_wgrad_f16x3(const WgradArgs& a0, hipStream_t st) {
   WgradArgs a = a0;
   if (!wgrad_f16x3_applicable(a)) return hipErrorInvalidValue;
+  const int wx = wgrad_f16x3_wx(a);
   const int pairs = ((a.wrows + 63) / 64) * (a.Ctot / 32);
-  const int nstages = a.N * (a.Ho / kWR) * (a.Wo / kWX);
-  // one 512-thread workgroup per CU; at least 4 stages per split (the two-stage prefetch needs a few to pay)
+  const int nstages = a.N * (a.Ho / (128 / wx)) * (a.Wo / wx);
+  // one 768-thread workgroup per CU; at least 4 stages per split (the two-stage prefetch needs a few to pay)
   const int cus = device_cu_count();
   int nsplit = (cus + pairs - 1) / pairs;
   if (nsplit > nstages / 4) nsplit = nstages / 4;
@@ -283,16 +305,10 @@ hipError_t launch_wgrad_f16x3(const WgradArgs& a0, hipStream_t st) {
   const int sps = (nstages + nsplit - 1) / nsplit;
   nsplit = (nstages + sps - 1) / sps;
   a.nsplit = nsplit; a.msplit = sps;
-  const size_t lds = (size_t)2 * kWStage;
-  static DevOnce lds_attr;
-  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_f16x3_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(43, a.flops, a.bytes, wgrad_f16x3_kernel, dim3((unsigned)(pairs * nsplit)), dim3(768), lds, st, a, sps, nstages);
-  if (nsplit > 1) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return launch_wgrad_reduce(a.part, nsplit, image / 4, a.dw, st, a.rq);
-  }
-  return hipGetLastError();
+  hipError_t e = wx == 32 ? launch_wg16<32>(a, st, pairs, sps, nstages) : launch_wg16<16>(a, st, pairs, sps, nstages);
+  if (e != hipSuccess) return e;
+  if (nsplit > 1) return launch_wgrad_reduce(a.part, nsplit, image / 4, a.dw, st, a.rq);
+  return hipSuccess;
 }
 
 }  // namespace uwm
