@@ -233,10 +233,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- patch staging through registers: 1296 16-byte units (pixel, channel quad) = 6 rounds; a round's geometry is one packed
-  // word (clamped row, clamped column, in-bounds bit) — the source offset is rebuilt from it per chunk (the two sources of a
-  // concat differ in size when one of them is up-sampled)
-  unsigned geo[kFRounds];
+  // ---- patch staging through registers: 1296 16-byte units (pixel, channel quad) = 6 rounds
+  // (a round's source offsets are stage-invariant: computed once for either source of the concat — they differ in size when one
+  // of them is up-sampled — so that a chunk's loads cost one add each; the in-bounds / active bits sit in one flag word)
+  int goff0[kFRounds], goff1[kFRounds];
+  unsigned gflags = 0;
 #pragma unroll
   for (int rd = 0; rd < kFRounds; ++rd) {
     const int u = rd * 256 + tid;
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
     const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
     const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
-    geo[rd] = ((unsigned)hc << 16) | (unsigned)wc | (ok ? 0x80000000u : 0u) | (act ? 0x00008000u : 0u);
+    goff0[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
+    goff1[rd] = a.C0 < a.Ctot ? ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C : goff0[rd];
+    gflags |= ((ok ? 1u : 0u) | (act ? 2u : 0u)) << (2 * rd);
   }
   // dgrad: dY is tiny (1e-3 ... 1e-9): it is staged times the power of two that puts max|dY| into [2^13, 2^14) (exact; undone in
   // the epilogue).  max|dY| = the maximum of the 32 slots bn_bwd_apply filled; activations are staged as they are
@@ -268,11 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     if (phas) { psc = *(const f4*)(s.scale + cl); psh = *(const f4*)(s.shift + cl); }
     const float* sp = s.ptr + cl;
 #pragma unroll
-    for (int rd = 0; rd < kFRounds; ++rd) {
-      const int hc = (int)((geo[rd] >> 16) & 0x7fffu), wc = (int)(geo[rd] & 0x7fffu);
-      const size_t off = (((size_t)n * s.H + (hc >> s.up)) * s.W + (wc >> s.up)) * s.C;
-      pv[rd] = *(const f4*)(sp + off);
-    }
+    for (int rd = 0; rd < kFRounds; ++rd) pv[rd] = *(const f4*)(sp + (first ? goff0[rd] : goff1[rd]));
   };
   auto patch_store = [&](int buf) {
 #pragma unroll
@@ -283,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
         if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
       v = v * xs;
-      if (!(geo[rd] & 0x80000000u)) v = (f4){0.f, 0.f, 0.f, 0.f};
-      if (geo[rd] & 0x00008000u) {
+      if (!((gflags >> (2 * rd)) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+      if ((gflags >> (2 * rd)) & 2u) {
         h4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -495,7 +494,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
 
   if (!is_mma) {
     // ================= loader waves =================
-    unsigned geo[kFRounds];
+    int goff0[kFRounds], goff1[kFRounds];                // stage-invariant source offsets of a round, per source of the concat
+    unsigned gflags = 0;
 #pragma unroll
     for (int rd = 0; rd < kFRounds; ++rd) {
       const int u = rd * 256 + ltid;
@@ -505,7 +505,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
       const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
       const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
       const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
-      geo[rd] = ((unsigned)hc << 16) | (unsigned)wc | (ok ? 0x80000000u : 0u) | (act ? 0x00008000u : 0u);
+      goff0[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
+      goff1[rd] = a.C0 < a.Ctot ? ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C : goff0[rd];
+      gflags |= ((ok ? 1u : 0u) | (act ? 2u : 0u)) << (2 * rd);
     }
     struct Stage { f4 pv[kFRounds]; f4 sc, sh; int relu; bool has; };
     auto patch_load = [&](int cc, Stage& st) {
@@ -518,11 +520,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
       if (st.has) { st.sc = *(const f4*)(s.scale + cl); st.sh = *(const f4*)(s.shift + cl); }
       const float* sp = s.ptr + cl;
 #pragma unroll
-      for (int rd = 0; rd < kFRounds; ++rd) {
-        const int hc = (int)((geo[rd] >> 16) & 0x7fffu), wc = (int)(geo[rd] & 0x7fffu);
-        const size_t off = (((size_t)n * s.H + (hc >> s.up)) * s.W + (wc >> s.up)) * s.C;
-        st.pv[rd] = *(const f4*)(sp + off);
-      }
+      for (int rd = 0; rd < kFRounds; ++rd) st.pv[rd] = *(const f4*)(sp + (first ? goff0[rd] : goff1[rd]));
     };
     auto patch_store = [&](int buf, const Stage& st) {
 #pragma unroll
@@ -533,8 +531,8 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
           if (st.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         }
         v = v * xs;
-        if (!(geo[rd] & 0x80000000u)) v = (f4){0.f, 0.f, 0.f, 0.f};
-        if (geo[rd] & 0x00008000u) {
+        if (!((gflags >> (2 * rd)) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+        if ((gflags >> (2 * rd)) & 2u) {
           h4 hi, lo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -489,12 +489,13 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
 }
 
 // a conv takes the fp16x3 direct kernel (forward) when its shape is eligible AND the launch fills the chip: 16x16-pixel x 64-channel
-// workgroups, at least one per CU (layer4-sized launches at small batch / resolution stay on the Winograd kernels)
+// workgroups, at least one per two CUs (measured: 973 vs 952 img/s with layer4's 128-workgroup launches on it; smaller launches
+// — small batch / resolution — stay on the Winograd kernels)
 static bool f3_fwd_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec < UWM_PREC_F16X3 || !cv.f3() || !p.wino_ok(ci)) return false;
   const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
-  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count());
+  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
 }
 // a decoder conv1's dgrad splits the concat gradient in its epilogue (ConvArgs::out_up): the fp16x3 kernel takes it when the
 // boundary sits on a 64-channel tile
@@ -513,7 +514,7 @@ static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec != UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
   const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
-  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count());
+  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
 }
 // ------------------------------------------------------------------------------ launch helpers
 struct Ctx {

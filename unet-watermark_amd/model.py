@@ -241,7 +241,7 @@ class Unet(nn.Module):
         if mode not in L.PREC:
             raise ValueError(f"unsupported precision {mode!r} (supported: {list(L.PREC)})")
         L.check(L.lib().uwm_set_precision(self._h, L.PREC[mode]), ValueError)
-        if min_workgroups is not None:       # fp16x3 modes: smallest launch the fp16x3 kernels take (default: one workgroup per CU)
+        if min_workgroups is not None:       # fp16x3 modes: smallest launch the fp16x3 kernels take (default: one workgroup per two CUs)
             L.check(L.lib().uwm_set_precision_fill(self._h, int(min_workgroups)), ValueError)
         self.precision = mode
         return self
