@@ -756,6 +756,12 @@ def test_conv_f16x3_direct(cuda, shape):
     n, cin, cout, h, w = shape
     _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=600)
     _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=600, lazy=True, seed=5)
+    # the launcher picks the kernel by launch size (these shapes are small: the eight-wave kernel); force the other ones too:
+    # 601 = four waves, 64-channel tiles; 603 = four waves, 32-channel tiles (the 32-output layers)
+    _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=601, lazy=True, seed=6)
+    _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=602, seed=7)
+    _conv_case(cuda, n, cin, cout, h, w, 3, 1, 1, cfg=603, lazy=True, seed=8)
+    _conv_case(cuda, n, cin, 32, h, w, 3, 1, 1, cfg=603, seed=9)
 
 
 def test_conv_f16x3_error_vs_fp64_and_range(cuda):

@@ -210,7 +210,12 @@ __device__ __forceinline__ void f16x3_split_epilogue(const ConvArgs& a, const fl
 // ---------------------------------------------------------------- main kernel
 __device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
 
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
+// NJ = 16-channel fragments per workgroup: 4 (64 output channels) or 2 (32: the 32-output layers of decoder block 3 — half of a
+// 64-channel tile's MFMAs and filter loads were padding there: 400 / 162 us forward against 416 / 152 on the fp32 Winograd kernel)
+template <int NJ>
+__global__ __launch_bounds__(256, (NJ == 2 ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
+  constexpr int kCo = 16 * NJ;                         // output channels per workgroup
+  constexpr int kCQ = 4 * NJ, kSub = 64 / kCQ;        // epilogue: lanes along the channel quads x pixel sub-rows
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];      // [2][324 px][40 halfs]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,19 +224,19 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   const unsigned nblk = gridDim.x, bid = blockIdx.x;
   const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
   unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tilesN = (a.Cout + 63) / 64;
+  const int tilesN = (a.Cout + kCo - 1) / kCo;
   const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
   const int tn = tile % tilesN; tile /= tilesN;
   const int tw = tile % tilesW; tile /= tilesW;
   const int th = tile % tilesH; const int n = tile / tilesH;
-  const int n0 = tn * 64, h0 = th * kFT, w0 = tw * kFT;
+  const int n0 = tn * kCo, h0 = th * kFT, w0 = tw * kFT;
   const int nJ = a.wu_ncb;
 
-  f4 acc[4][4];
+  f4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
   // ---- patch staging through registers: 1296 16-byte units (pixel, channel quad) = 6 rounds
   // (a round's source offsets are stage-invariant: computed once for either source of the concat — they differ in size when one
@@ -303,43 +308,43 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   const _Float16* const wb = (const _Float16*)a.wu + (size_t)(n0 / 16) * 1024 + lane * 8;
   const int nchunk = a.Ctot >> 4, nsteps = nchunk * kFKs;
   constexpr int dbg = UWM_F16_ABL;
-  auto w_load = [&](int t, h8 (&whi)[4], h8 (&wlo)[4]) {
+  auto w_load = [&](int t, h8 (&whi)[NJ], h8 (&wlo)[NJ]) {
     if ((dbg & 2) && t > 0) return;
     const _Float16* p = wb + (size_t)t * nJ * 1024;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { whi[j] = *(const h8*)(p + j * 1024); wlo[j] = *(const h8*)(p + j * 1024 + 512); }
+    for (int j = 0; j < NJ; ++j) { whi[j] = *(const h8*)(p + j * 1024); wlo[j] = *(const h8*)(p + j * 1024 + 512); }
   };
   // ---- pixel fragments: lane (pixel column px16, group g) reads 8 channels of tap slot 2*ks + (g >> 1) at pixel row 4*wave + i
   const int pbase = ((wave * 4) * kFP + px16) * kFPix + (g & 1) * 8;
   const int ghi = g >> 1;
-  auto mma_step = [&](int ks, const _Float16* pc, const h8 (&whi)[4], const h8 (&wlo)[4]) {
+  auto mma_step = [&](int ks, const _Float16* pc, const h8 (&whi)[NJ], const h8 (&wlo)[NJ]) {
     const int slot0 = 2 * ks, slot1 = 2 * ks + 1 > 8 ? 8 : 2 * ks + 1;      // (slot 9: its weights are zero; read a valid address)
     const int off0 = ((slot0 / 3) * kFP + slot0 % 3) * kFPix, off1 = ((slot1 / 3) * kFP + slot1 % 3) * kFPix;
     const _Float16* pp = pc + pbase + (ghi ? off1 : off0);
     h8 xh[4], xl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (dbg & 4) { xh[i] = whi[i]; xl[i] = wlo[i]; continue; }
+      if (dbg & 4) { xh[i] = whi[i % NJ]; xl[i] = wlo[i % NJ]; continue; }
       xh[i] = *(const h8*)(pp + i * kFP * kFPix); xl[i] = *(const h8*)(pp + i * kFP * kFPix + 16);
     }
-    if (dbg & 1) { acc[0][0][0] += (float)xh[0][0] + (float)xl[1][1] + (float)whi[2][2] + (float)wlo[3][3] + (float)xh[2][0] + (float)xh[3][0]; return; }
+    if (dbg & 1) { acc[0][0][0] += (float)xh[0][0] + (float)xl[1][1] + (float)whi[NJ - 2][2] + (float)wlo[NJ - 1][3] + (float)xh[2][0] + (float)xh[3][0]; return; }
     // the three products of a tile go to the SAME accumulator: issue them 16 tiles apart (a dependent MFMA waits ~2 issue
     // slots for its predecessor's result), product type outermost
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
   };
 
-  h8 wA_hi[4], wA_lo[4], wB_hi[4], wB_lo[4];
+  h8 wA_hi[NJ], wA_lo[NJ], wB_hi[NJ], wB_lo[NJ];
   w_load(0, wA_hi, wA_lo);
   patch_load(0);
   patch_store(0);
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
       __syncthreads();
     }
   }
-  if (dbg & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[2][2][2] + acc[3][3][3] == 123.456f) a.out[0] = 1.f; return; }
+  if (dbg & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[2][NJ - 2][2] + acc[3][NJ - 1][3] == 123.456f) a.out[0] = 1.f; return; }
 
   // ---------------- epilogue: D[row = co 4g + e][col = pixel px16].  A lane holds 4 channels of one pixel per tile: stored
   // straight from the accumulators a wave instruction writes sixteen 64-byte pieces (half cache lines: 49 of the 94 us of a
@@ -377,18 +382,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(f4*)(R + (i * 16 + px16) * kQLd + j * 16 + g * 4) = acc[i][j];
+    for (int j = 0; j < NJ; ++j) *(f4*)(R + (i * 16 + px16) * kQLd + j * 16 + g * 4) = acc[i][j];
   __syncthreads();
   const float* rinv = (const float*)a.wu + a.wu_rinv_off;
   const float ixs = 1.f / xs;
   const bool do_stats = a.ssum != nullptr;
   const bool bnb = a.bnb_mean != nullptr;
-  const int cq = lane & 15, sub = lane >> 4;
+  const int cq = lane & (kCQ - 1), sub = lane / kCQ;
   const int co = n0 + cq * 4;
   const bool cok = co < a.Cout;
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
   const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;       // channels the statistics cover
-  if (a.out_up != nullptr) {
+  if (NJ == 4 && a.out_up != nullptr) {                 // (the concat split works on 64-channel tiles: the launcher keeps it on NJ = 4)
     f4 rs = {0.f, 0.f, 0.f, 0.f};
     if (cok) rs = *(const f4*)(rinv + co) * ixs;
     f16x3_split_epilogue<4>(a, R, kQLd, 0, n, h0 + wave * 4, w0, n0, lane, rs, ps_, pq_);
@@ -399,8 +404,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     if (a.bias && cok) bia = *(const f4*)(a.bias + co);
     if (a.mscale && cok) { msc = *(const f4*)(a.mscale + co); msh = *(const f4*)(a.mshift + co); }
 #pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-      const int p = r * 4 + sub;
+    for (int r = 0; r < 64 / kSub; ++r) {
+      const int p = r * kSub + sub;
       const int ho = h0 + wave * 4 + (p >> 4), wo = w0 + (p & 15);
       if (ho < a.Ho && wo < a.Wo && cok) {
         const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
@@ -425,8 +430,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float sv = ps_[e], qv = pq_[e];
-      sv += __shfl_xor(sv, 16); qv += __shfl_xor(qv, 16);
-      sv += __shfl_xor(sv, 32); qv += __shfl_xor(qv, 32);
+#pragma unroll
+      for (int d = kCQ; d < 64; d <<= 1) { sv += __shfl_xor(sv, d); qv += __shfl_xor(qv, d); }
       ps_[e] = sv; pq_[e] = qv;
     }
     __syncthreads();                             // every wave is done with its block
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
       for (int e = 0; e < 4; ++e) { red[(wave * 64 + cq * 4 + e) * 2] = ps_[e]; red[(wave * 64 + cq * 4 + e) * 2 + 1] = pq_[e]; }
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < kCo) {
       const int c1 = n0 + tid;
       if (c1 < stat_c) {
         double sv = 0.0, qv = 0.0;
@@ -715,7 +720,7 @@ bool conv_f16x3_applicable(const ConvArgs& a) {
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
 }
 
-hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st) {
+hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   if (!conv_f16x3_applicable(a)) return hipErrorInvalidValue;
   if (a.out_up && (a.addend || a.mask || a.bias || a.bnb_y || (a.ssum && !a.bnb_mean) || (a.up_c0 < a.Cout && !a.out))) return hipErrorInvalidValue;
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum)) return hipErrorInvalidValue;
@@ -723,17 +728,24 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st) {
   const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
   const size_t main_lds = (size_t)2 * kFBuf * sizeof(_Float16), q_lds = (size_t)4 * 64 * 68 * sizeof(float);
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
-  static DevOnce lds_attr;
-  { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3_kernel, lds); if (e != hipSuccess) return e; }
   // 8-wave kernel (one workgroup per CU, loader waves beside the MMA waves) for launches with fewer than two workgroups per CU
   // — long-K deep layers, where staging under the MFMAs pays (layer3 93 -> 79 us, layer4 159 -> 124, 768 -> 256 at 32^2 226 -> 198);
   // the 4-wave kernel (two workgroups per CU hide each other's prologue and epilogue) for the many-tile, short-K ones
   // (layer1 89 vs 93 us, layer2 73 vs 77)
   static const bool force4 = dbg_flag("UWM_F16X3_4WAVE"), force8 = dbg_flag("UWM_F16X3_8WAVE");
   const long wgs = (long)a.N * tilesH * tilesW * tilesN;
-  const bool four = force4 || (!force8 && wgs >= 2L * device_cu_count());
+  const bool four = variant == 1 || variant == 3 || (variant != 2 && (force4 || (!force8 && wgs >= 2L * device_cu_count())));
+  if (variant == 3 && a.out_up) return hipErrorInvalidValue;
+  if (variant == 3 || (variant == 0 && four && a.Cout <= 32 && !a.out_up)) {                // 32-channel tiles: no padded fragments
+    static DevOnce lds_attr2;
+    { hipError_t e = lds_attr2.set_max_lds((const void*)conv_f16x3_kernel<2>, lds); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<2>), dim3((unsigned)(a.N * tilesH * tilesW * ((a.Cout + 31) / 32))), dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
   if (four) {
-    UWM_LAUNCH(42, a.flops, a.bytes, conv_f16x3_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
+    static DevOnce lds_attr;
+    { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3_kernel<4>, lds); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<4>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
     return hipGetLastError();
   }
   static DevOnce lds_attr_s;

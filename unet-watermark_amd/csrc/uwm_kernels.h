@@ -207,7 +207,7 @@ size_t f16x3_bank_floats(int rows, int chans);             // bank size in float
 size_t f16x3_rinv_off(int rows, int chans);                 // float offset of that array in the bank
 hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st);
 bool conv_f16x3_applicable(const ConvArgs& a);
-hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st);
+hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant = 0);      // variant: 0 auto | 1 four-wave kernel | 2 eight-wave kernel | 3 four-wave, 32-channel tiles (tests)
 bool conv_wino_x3_applicable(const ConvArgs& a);
 hipError_t launch_conv_wino_x3(const ConvArgs& a, hipStream_t st);
 // process default (UWM_WINOGRAD / uwm_set_winograd): used by the single-operator entry points and by handles created later

@@ -56,7 +56,9 @@ struct ConvL {
   bool x3() const { return wino() && (CinP & 15) == 0 && (c0 & 15) == 0; }
   bool x3_d() const { return wino_d() && (CoutP & 15) == 0; }
   // fp16x3 direct form (conv_f16x3.hip): chunk pairs of 16 channels on either side of the concat
-  bool f3() const { return wino() && (CinP & 31) == 0 && (c0 & 15) == 0 && Cout >= 16; }
+  // (Cout >= 32: the 16-output full-resolution layers have their own kernels — conv_up2 / conv_patch16 — which the 64-channel tile
+  // of conv_f16x3 cannot match: 565 vs 176 us on decoder block 4 conv1)
+  bool f3() const { return wino() && (CinP & 31) == 0 && (c0 & 15) == 0 && Cout >= 32; }
   bool f3_d() const { return wino_d() && (CoutP & 31) == 0 && CinP >= 16; }
 };
 // encoder residual block.  BasicBlock: c1 3x3(stride) -> c2 3x3, c3 = -1.  Bottleneck: c1 1x1 -> c2 3x3(stride) -> c3 1x1(x4).
@@ -507,7 +509,7 @@ static bool f3d_plain(const uwm_model* m, int ci) {
 // fp16x3 weight gradient: the map tiled by whole 4 x 32- or 8 x 16-pixel stages, 32-channel tiles on either side of the concat
 static bool f3_wgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
-  return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP &&
+  return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && cv.Cout >= 32 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP &&
          (((p.ow[ci] % 32) == 0 && (p.oh[ci] % 4) == 0) || ((p.ow[ci] % 16) == 0 && (p.oh[ci] % 8) == 0)) && !dbg_flag("UWM_NO_F16X3_WGRAD");
 }
 static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
@@ -1651,7 +1653,7 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
-  if (cfg == 600) {
+  if (cfg >= 600 && cfg <= 603) {                     // 600 auto | 601 four-wave kernel | 602 eight-wave kernel | 603 four-wave, 32-channel tiles
     if (!op_wino_shape(a, kh, kw, stride, pad)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs 3x3 s1 p1, Ho >= 8, Wo >= 16");
     if (op_f16x3_prepare(a, (hipStream_t)stream)) return 1;
   } else if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
