@@ -213,7 +213,7 @@ __device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504
 // NJ = 16-channel fragments per workgroup: 4 (64 output channels) or 2 (32: the 32-output layers of decoder block 3 — half of a
 // 64-channel tile's MFMAs and filter loads were padding there: 400 / 162 us forward against 416 / 152 on the fp32 Winograd kernel)
 template <int NJ>
-__global__ __launch_bounds__(256, (NJ == 2 ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   constexpr int kCo = 16 * NJ;                         // output channels per workgroup
   constexpr int kCQ = 4 * NJ, kSub = 64 / kCQ;        // epilogue: lanes along the channel quads x pixel sub-rows
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];      // [2][324 px][40 halfs]
@@ -238,11 +238,13 @@ __global__ __launch_bounds__(256, (NJ == 2 ? 3 : 2)) void conv_f16x3_kernel(cons
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- patch staging through registers: 1296 16-byte units (pixel, channel quad) = 6 rounds
-  // (a round's source offsets are stage-invariant: computed once for either source of the concat — they differ in size when one
-  // of them is up-sampled — so that a chunk's loads cost one add each; the in-bounds / active bits sit in one flag word)
-  int goff0[kFRounds], goff1[kFRounds];
+  // ---- patch staging through registers: 1296 16-byte units (pixel, channel quad) = 5 whole rounds of 256 + 16 units (threads 0-15).
+  // A round's source offset is chunk-invariant: held in registers for the source being read; the second source's (the two
+  // differ in size when one of them is up-sampled) wait in LDS until the chunk walk crosses the concat boundary (recomputing
+  // them there cost 28 spilled VGPRs); the in-bounds bits sit in one flag word
+  int goff[kFRounds];
   unsigned gflags = 0;
+  int* const goff_s1 = (int*)(hsm + 2 * kFBuf);          // [6][256] behind the patch buffers: the second source's offsets, parked in LDS
 #pragma unroll
   for (int rd = 0; rd < kFRounds; ++rd) {
     const int u = rd * 256 + tid;
@@ -252,9 +254,9 @@ __global__ __launch_bounds__(256, (NJ == 2 ? 3 : 2)) void conv_f16x3_kernel(cons
     const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
     const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
     const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
-    goff0[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
-    goff1[rd] = a.C0 < a.Ctot ? ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C : goff0[rd];
-    gflags |= ((ok ? 1u : 0u) | (act ? 2u : 0u)) << (2 * rd);
+    goff[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
+    if (a.C0 < a.Ctot) goff_s1[rd * 256 + tid] = ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C;      // (read back by this thread only)
+    gflags |= (ok ? 1u : 0u) << rd;
   }
   // dgrad: dY is tiny (1e-3 ... 1e-9): it is staged times the power of two that puts max|dY| into [2^13, 2^14) (exact; undone in
   // the epilogue).  max|dY| = the maximum of the 32 slots bn_bwd_apply filled; activations are staged as they are
@@ -265,43 +267,50 @@ __global__ __launch_bounds__(256, (NJ == 2 ? 3 : 2)) void conv_f16x3_kernel(cons
     for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
     if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
   }
-  f4 pv[kFRounds], psc, psh; int prelu = 0; bool phas = false;
-  auto patch_load = [&](int cc) {
+  // Two register sets of raw patch values (chunks c+1 and c+2 in flight while chunk c is multiplied) and ONE set of lazy-transform
+  // coefficients (those of the chunk being stored).  The store side is branch-free and cut into rounds, so that a round's
+  // conversion work (about 30 VALU instructions + 2 LDS stores) can sit in the shadow of a tap pair's MFMAs — the matrix pipe
+  // and the VALU do not co-execute across waves here (PMC: SQ_VALU_MFMA_COEXEC_CYCLES = 6 % of the MFMA-busy cycles with the
+  // staging as a phase of its own; 2.8 VALU instructions per MFMA, i.e. 70 % of the MFMA time again, back to back)
+  constexpr int kWR = kFRounds - 1;                    // whole rounds (5); the 16 left-over units: pvX, threads 0-15
+  f4 pv[kWR], pvX = {0.f, 0.f, 0.f, 0.f}, psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  float pfloor = -3.0e38f;                               // ReLU as max(v, floor): 0 or "-inf"
+  const bool has_x = tid < kFPP * 4 - kWR * 256;
+  const float* lsp = nullptr;                            // source pointer of the chunk whose loads are being issued
+  auto chunk_src = [&](int cc) {
+    const int c = cc * 16;
+    const bool first = c < a.C0;
+    if (c == a.C0 && a.C0 < a.Ctot) {                    // the walk crosses the concat boundary (chunks are visited in order)
+#pragma unroll
+      for (int rd = 0; rd < kFRounds; ++rd) goff[rd] = goff_s1[rd * 256 + tid];
+    }
+    lsp = (first ? a.s0.ptr : a.s1.ptr) + (first ? c : c - a.C0) + (tid & 3) * 4;
+  };
+  auto coef_load = [&](int cc) {
     const int c = cc * 16;
     const bool first = c < a.C0;
     const Src& s = first ? a.s0 : a.s1;
-    prelu = s.relu;
     const int cl = (first ? c : c - a.C0) + (tid & 3) * 4;
-    phas = s.scale != nullptr;
-    if (phas) { psc = *(const f4*)(s.scale + cl); psh = *(const f4*)(s.shift + cl); }
-    const float* sp = s.ptr + cl;
-#pragma unroll
-    for (int rd = 0; rd < kFRounds; ++rd) pv[rd] = *(const f4*)(sp + (first ? goff0[rd] : goff1[rd]));
+    pfloor = s.relu ? 0.f : -3.0e38f;
+    if (s.scale != nullptr) { psc = *(const f4*)(s.scale + cl); psh = *(const f4*)(s.shift + cl); }
+    else { psc = (f4){1.f, 1.f, 1.f, 1.f}; psh = (f4){0.f, 0.f, 0.f, 0.f}; pfloor = -3.0e38f; }
   };
-  auto patch_store = [&](int buf) {
+  auto store_unit = [&](int buf, int rd, f4 raw) {
+    f4 v = raw * psc + psh;
+    v.x = fmaxf(v.x, pfloor); v.y = fmaxf(v.y, pfloor); v.z = fmaxf(v.z, pfloor); v.w = fmaxf(v.w, pfloor);
+    v = v * xs;
+    if (!((gflags >> rd) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+    h4 hi, lo;
 #pragma unroll
-    for (int rd = 0; rd < kFRounds; ++rd) {
-      f4 v = pv[rd];
-      if (phas) {
-        v = v * psc + psh;
-        if (prelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      }
-      v = v * xs;
-      if (!((gflags >> (2 * rd)) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
-      if ((gflags >> (2 * rd)) & 2u) {
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = clamp_h(v[e]);
-          const _Float16 h = (_Float16)x;
-          hi[e] = h; lo[e] = (_Float16)(x - (float)h);
-        }
-        const int u = rd * 256 + tid;
-        _Float16* d = hsm + buf * kFBuf + (u >> 2) * kFPix + (u & 3) * 4;
-        *(h4*)d = hi;
-        *(h4*)(d + 16) = lo;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const float x = clamp_h(v[e]);
+      const _Float16 h = (_Float16)x;
+      hi[e] = h; lo[e] = (_Float16)(x - (float)h);
     }
+    const int u = rd * 256 + tid;
+    _Float16* d = hsm + buf * kFBuf + (u >> 2) * kFPix + (u & 3) * 4;
+    *(h4*)d = hi;
+    *(h4*)(d + 16) = lo;
   };
 
   // ---- filter fragments: global -> registers, one tap pair ahead.  step t = chunk * 5 + ks
@@ -346,27 +355,61 @@ __global__ __launch_bounds__(256, (NJ == 2 ? 3 : 2)) void conv_f16x3_kernel(cons
 
   h8 wA_hi[NJ], wA_lo[NJ], wB_hi[NJ], wB_lo[NJ];
   w_load(0, wA_hi, wA_lo);
-  patch_load(0);
-  patch_store(0);
+  chunk_src(0);
+#pragma unroll
+  for (int rd = 0; rd < kWR; ++rd) pv[rd] = *(const f4*)(lsp + goff[rd]);
+  if (has_x) pvX = *(const f4*)(lsp + goff[kWR]);
+  coef_load(0);
+#pragma unroll
+  for (int rd = 0; rd < kWR; ++rd) store_unit(0, rd, pv[rd]);
+  if (has_x) store_unit(0, kWR, pvX);
+  if (nchunk > 1) {                                      // chunk 1 (it may already be the second source)
+    chunk_src(1);
+#pragma unroll
+    for (int rd = 0; rd < kWR; ++rd) pv[rd] = *(const f4*)(lsp + goff[rd]);
+    if (has_x) pvX = *(const f4*)(lsp + goff[kWR]);
+  }
   __syncthreads();
 
-  // two chunks (10 tap pairs) per iteration so that the two register sets of filter fragments alternate statically
+  // Iteration c multiplies chunk c (buffer c & 1) and, inside the MFMA stream, one round per tap pair: converts and stores round
+  // ks of chunk c+1 (its raw values arrived during iteration c-1) into the other buffer and re-issues that register's global load
+  // for chunk c+2 — a full iteration of latency budget with ONE register set.  Two chunks per loop trip: the filter-fragment
+  // register sets alternate statically.
   for (int cc = 0; cc < nchunk; cc += 2) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int c = cc + hh, cur = hh, nxt = hh ^ 1;       // (nchunk is even: chunk c sits in buffer c & 1 = hh)
-      const int cn = c + 1 < nchunk ? c + 1 : c;           // last chunk: harmless re-fetch into the dead buffer
-      if (!(dbg & 8)) patch_load(cn);
+      const bool more1 = c + 1 < nchunk;
+      coef_load(more1 ? c + 1 : c);
+      chunk_src(c + 2 < nchunk ? c + 2 : nchunk - 1);      // (past the end: a harmless re-fetch)
       const _Float16* pc = hsm + cur * kFBuf;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < kFKs; ++ks) {
         const int t = c * kFKs + ks;
         const int tnext = t + 1 < nsteps ? t + 1 : t;
         if (((hh * kFKs + ks) & 1) == 0) { w_load(tnext, wB_hi, wB_lo); mma_step(ks, pc, wA_hi, wA_lo); }
         else { w_load(tnext, wA_hi, wA_lo); mma_step(ks, pc, wB_hi, wB_lo); }
+        if (!(dbg & 8)) {
+          store_unit(nxt, ks, pv[ks]);                     // (past the last chunk: into the dead buffer)
+          pv[ks] = *(const f4*)(lsp + goff[ks]);
+        }
+        // schedule of the tap pair: filter loads and fragment reads first, then the round's VALU work spread under the MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * NJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int q = 0; q < 4 * NJ; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!(dbg & 8)) patch_store(nxt);
+      if (!(dbg & 8) && has_x) {
+        if (more1) store_unit(nxt, kWR, pvX);
+        pvX = *(const f4*)(lsp + goff[kWR]);
+      }
       __syncthreads();
     }
   }
@@ -726,7 +769,7 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum)) return hipErrorInvalidValue;
   const int tilesN = (a.Cout + 63) / 64;
   const int tilesW = (a.Wo + kFT - 1) / kFT, tilesH = (a.Ho + kFT - 1) / kFT;
-  const size_t main_lds = (size_t)2 * kFBuf * sizeof(_Float16), q_lds = (size_t)4 * 64 * 68 * sizeof(float);
+  const size_t main_lds = (size_t)2 * kFBuf * sizeof(_Float16) + 6 * 256 * sizeof(int), q_lds = (size_t)4 * 64 * 68 * sizeof(float);
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
   // 8-wave kernel (one workgroup per CU, loader waves beside the MMA waves) for launches with fewer than two workgroups per CU
   // — long-K deep layers, where staging under the MFMAs pays (layer3 93 -> 79 us, layer4 159 -> 124, 768 -> 256 at 32^2 226 -> 198);

@@ -29,7 +29,7 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.mg);
 }
 
-// PC = stride-2 dgrad by output-pixel parity class (blockIdx.y = 2*pc_h + pc_w): a workgroup covers only the pixels
+// PC = stride-2 dgrad by output-pixel parity class (class 2*pc_h + pc_w = 3 - blockIdx.y: the four-tap class of a 3x3 is dispatched first): a workgroup covers only the pixels
 // (2i + pc_h, 2j + pc_w) and walk only the taps that reach an input pixel from that class (1, 2, 2 or 4 of the
 // nine; pc_taps lists them) — the plain transposed gather spends 3/4 of its MFMAs on taps its pixels cannot use.
 template <int BM, int BN, int WM, int WN, bool PC = false>
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     int mm = v ? m : 0;
     int n = mm / HoWo, rem = mm - n * HoWo;
     int ho = rem / Wg, wo = rem - ho * Wg;
-    if (PC) { ho = 2 * ho + (int)(blockIdx.y >> 1); wo = 2 * wo + (int)(blockIdx.y & 1); }
+    if (PC) { ho = 2 * ho + (int)((3u - blockIdx.y) >> 1); wo = 2 * wo + (int)((3u - blockIdx.y) & 1); }
     rn[i] = n; rh[i] = ho * a.smul + a.off; rw[i] = wo * a.smul + a.off;
     rvalid |= (v ? 1u : 0u) << i;
   }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int cpt = PC ? (a.Ctot >> 5) : 1;                    // PC: 32-float chunks per tap (Ctot % 32 == 0)
   auto load_chunk = [&](int kci) {
     int kc = kci;
-    if (PC) { const int ti = kci / cpt; kc = ((a.pc_taps[blockIdx.y] >> (4 * ti)) & 15) * cpt + (kci - ti * cpt); }
+    if (PC) { const int ti = kci / cpt; kc = ((a.pc_taps[3u - blockIdx.y] >> (4 * ti)) & 15) * cpt + (kci - ti * cpt); }
     const unsigned k = kc * 32 + unit * 4;
     const unsigned tap = fdiv(k, a.dv_ctot);
     const int c = k - tap * a.Ctot;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   };
 
-  const int nk = PC ? a.pc_ntaps[blockIdx.y] * cpt : (a.Kpad >> 5);
+  const int nk = PC ? a.pc_ntaps[3u - blockIdx.y] * cpt : (a.Kpad >> 5);
   if (nk > 0) {
     load_chunk(0);
     store_chunk(0);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (PC && mv) {                                // class-grid index -> real output pixel
       const int n = m / HoWo, rem = m - n * HoWo;
       const int hi = rem / Wg, wi = rem - hi * Wg;
-      m = (n * a.Ho + 2 * hi + (int)(blockIdx.y >> 1)) * a.Wo + 2 * wi + (int)(blockIdx.y & 1);
+      m = (n * a.Ho + 2 * hi + (int)((3u - blockIdx.y) >> 1)) * a.Wo + 2 * wi + (int)((3u - blockIdx.y) & 1);
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -385,7 +385,13 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
     return launch_conv_patch(a, st, bn);
   }
   if (cfg < 0 && conv_s2_dgrad_applicable(a))
+  {
+    // the four classes carry 1 / 2 / 2 / 4 of a 3x3's taps, so the launch is as long as its four-tap class: when that class alone
+    // has fewer 128-wide tiles than CUs (layer3 / layer4 at batch 16: 128 / 64 workgroups, 169 / 233 us), 64 x 64 tiles
+    const long t128 = (long)((a.N * (a.Ho >> 1) * (a.Wo >> 1) + 127) / 128) * ((a.Cout + 127) / 128);
+    if (a.Cout > 64 && t128 < device_cu_count()) return launch_s2_dgrad<64, 64, 2, 2>(a, st, 4);
     return a.Cout <= 64 ? launch_s2_dgrad<128, 64, 2, 2>(a, st, 1) : launch_s2_dgrad<128, 128, 2, 2>(a, st, 0);
+  }
   if (cfg < 0 && conv_gemm_preferred(a)) return launch_conv_gemm(a, st, 0);      // 1x1 / stride 1, Cin % 32 == 0: persistent LDS-DMA GEMM
   if (cfg < 0) {
     const long tiles128 = (long)((a.M + 127) / 128);
