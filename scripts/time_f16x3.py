@@ -27,7 +27,7 @@ for name, cin, cout, h in (("layer1", 64, 64, 128), ("layer2", 128, 128, 64), ("
     st = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
     s0 = src(x)
     res = {}
-    for tag, cfg in (("wino", -1), ("f16x3", 600)):
+    for tag, cfg in (("wino", -1), ("f16x3", int(sys.argv[1]) if len(sys.argv) > 1 else 600)):      # 601 / 602 / 603: force a kernel variant
         f = lambda: L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(w), cout, rup(9 * cin, 32), 3, 3, 1, 1, N, cout, None, P(y), P(st), cfg, stream()))
         res[tag] = timeit(f)
     fl = 2.0 * N * h * h * cin * cout * 9
