@@ -764,6 +764,14 @@ def test_conv_f16x3_direct(cuda, shape):
     _conv_case(cuda, n, cin, 32, h, w, 3, 1, 1, cfg=603, seed=9)
 
 
+def test_conv_f16x3_single_chunk_16_to_16(cuda):
+    """the single-chunk form of conv_f16x3 (16 -> 16 channels: decoder block 4 conv2), plain and with a lazy BatchNorm + ReLU input,
+    whole and partial 16x16 tiles."""
+    for n, h, w in ((2, 32, 48), (1, 24, 40), (3, 16, 16)):
+        _conv_case(cuda, n, 16, 16, h, w, 3, 1, 1, cfg=600, seed=h)
+        _conv_case(cuda, n, 16, 16, h, w, 3, 1, 1, cfg=600, lazy=True, seed=h + 1)
+
+
 def test_conv_f16x3_error_vs_fp64_and_range(cuda):
     """fp16x3 keeps 22 mantissa bits per operand: against an fp64 convolution its error must stay within 4x the exact-fp32
     direct kernel's (the bf16x3 kernel's is ~30x) — and that must hold when the operands sit far from fp16's comfortable range:

@@ -212,8 +212,13 @@ __device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504
 
 // NJ = 16-channel fragments per workgroup: 4 (64 output channels) or 2 (32: the 32-output layers of decoder block 3 — half of a
 // 64-channel tile's MFMAs and filter loads were padding there: 400 / 162 us forward against 416 / 152 on the fp32 Winograd kernel)
+// NJ = 1: the 16 -> 16-channel full-resolution layer of decoder block 4 (conv2, forward and dgrad): ONE 16-channel chunk, so no
+// staging inside the loop, one patch buffer, a [64 px][20]-float epilogue block per wave — 26 KB of LDS and ~100 VGPRs: up to
+// six short-lived workgroups per CU cover each other's load latency (the fp32 conv_patch16 kernel is bound by its matrix pipe
+// there: 123 us of fp32 MFMAs against a 107-us HBM floor)
 template <int NJ>
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (NJ == 1 ? 4 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
+  constexpr bool kOne = NJ == 1;                       // single-chunk form
   constexpr int kCo = 16 * NJ;                         // output channels per workgroup
   constexpr int kCQ = 4 * NJ, kSub = 64 / kCQ;        // epilogue: lanes along the channel quads x pixel sub-rows
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];      // [2][324 px][40 halfs]
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
     const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
     goff[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
-    if (a.C0 < a.Ctot) goff_s1[rd * 256 + tid] = ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C;      // (read back by this thread only)
+    if (!kOne && a.C0 < a.Ctot) goff_s1[rd * 256 + tid] = ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C;      // (read back by this thread only)
     gflags |= (ok ? 1u : 0u) << rd;
   }
   // dgrad: dY is tiny (1e-3 ... 1e-9): it is staged times the power of two that puts max|dY| into [2^13, 2^14) (exact; undone in
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
       if (dbg & 4) { xh[i] = whi[i % NJ]; xl[i] = wlo[i % NJ]; continue; }
       xh[i] = *(const h8*)(pp + i * kFP * kFPix); xl[i] = *(const h8*)(pp + i * kFP * kFPix + 16);
     }
-    if (dbg & 1) { acc[0][0][0] += (float)xh[0][0] + (float)xl[1][1] + (float)whi[NJ - 2][2] + (float)wlo[NJ - 1][3] + (float)xh[2][0] + (float)xh[3][0]; return; }
+    if (dbg & 1) { acc[0][0][0] += (float)xh[0][0] + (float)xl[1][1] + (float)whi[NJ > 1 ? NJ - 2 : 0][2] + (float)wlo[NJ - 1][3] + (float)xh[2][0] + (float)xh[3][0]; return; }
     // the three products of a tile go to the SAME accumulator: issue them 16 tiles apart (a dependent MFMA waits ~2 issue
     // slots for its predecessor's result), product type outermost
 #pragma unroll
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
   for (int rd = 0; rd < kWR; ++rd) store_unit(0, rd, pv[rd]);
   if (has_x) store_unit(0, kWR, pvX);
-  if (nchunk > 1) {                                      // chunk 1 (it may already be the second source)
+  if (!kOne && nchunk > 1) {                             // chunk 1 (it may already be the second source)
     chunk_src(1);
 #pragma unroll
     for (int rd = 0; rd < kWR; ++rd) pv[rd] = *(const f4*)(lsp + goff[rd]);
@@ -377,11 +382,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   // register sets alternate statically.
   for (int cc = 0; cc < nchunk; cc += 2) {
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < (kOne ? 1 : 2); ++hh) {
       const int c = cc + hh, cur = hh, nxt = hh ^ 1;       // (nchunk is even: chunk c sits in buffer c & 1 = hh)
       const bool more1 = c + 1 < nchunk;
-      coef_load(more1 ? c + 1 : c);
-      chunk_src(c + 2 < nchunk ? c + 2 : nchunk - 1);      // (past the end: a harmless re-fetch)
+      if (!kOne) {
+        coef_load(more1 ? c + 1 : c);
+        chunk_src(c + 2 < nchunk ? c + 2 : nchunk - 1);    // (past the end: a harmless re-fetch)
+      }
       const _Float16* pc = hsm + cur * kFBuf;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
         const int tnext = t + 1 < nsteps ? t + 1 : t;
         if (((hh * kFKs + ks) & 1) == 0) { w_load(tnext, wB_hi, wB_lo); mma_step(ks, pc, wA_hi, wA_lo); }
         else { w_load(tnext, wA_hi, wA_lo); mma_step(ks, pc, wB_hi, wB_lo); }
-        if (!(dbg & 8)) {
+        if (!(dbg & 8) && !kOne) {
           store_unit(nxt, ks, pv[ks]);                     // (past the last chunk: into the dead buffer)
           pv[ks] = *(const f4*)(lsp + goff[ks]);
         }
@@ -406,21 +413,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!(dbg & 8) && has_x) {
+      if (!(dbg & 8) && !kOne && has_x) {
         if (more1) store_unit(nxt, kWR, pvX);
         pvX = *(const f4*)(lsp + goff[kWR]);
       }
       __syncthreads();
     }
   }
-  if (dbg & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[2][NJ - 2][2] + acc[3][NJ - 1][3] == 123.456f) a.out[0] = 1.f; return; }
+  if (dbg & 16) { if (acc[0][0][0] + acc[1][1][1] + acc[2][NJ > 1 ? NJ - 2 : 0][2] + acc[3][NJ - 1][3] == 123.456f) a.out[0] = 1.f; return; }
 
   // ---------------- epilogue: D[row = co 4g + e][col = pixel px16].  A lane holds 4 channels of one pixel per tile: stored
   // straight from the accumulators a wave instruction writes sixteen 64-byte pieces (half cache lines: 49 of the 94 us of a
   // layer1 launch).  So every wave passes its 64 px x 64 ch block through LDS (its own region, [pixel][64 + 4 pad] floats; the
   // patch buffers are dead) and reads it back with lanes along the channels: 256 contiguous bytes per pixel, per-thread
   // constant channel quad (row un-scale, bias, mask coefficients and the statistics stay in registers)
-  constexpr int kQLd = 68;
+  constexpr int kQLd = kOne ? 20 : 68;
   float* const R = (float*)hsm + wave * 64 * kQLd;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
 // masked) but at least one; the fused concat split (ConvArgs::out_up) with the boundary on a 64-channel tile
 bool conv_f16x3_applicable(const ConvArgs& a) {
   return a.wu != nullptr && a.ntaps == 9 && a.kw == 3 && a.smul == 1 && a.sdiv == 1 && (a.rmul == 1 ? a.off == -1 : a.off == 1) &&
-         (a.Ctot & 31) == 0 && (a.C0 & 15) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && (a.Cout & 3) == 0 && a.Cout >= 16 &&
+         ((a.Ctot & 31) == 0 || (a.Ctot == 16 && a.C0 == 16 && a.Cout <= 16 && !a.out_up)) && (a.C0 & 15) == 0 && (a.s0.C & 3) == 0 && (a.s1.C & 3) == 0 && (a.Cout & 3) == 0 && a.Cout >= 16 &&
          a.Hl == a.Ho && a.Wl == a.Wo && a.Ho >= 8 && a.Wo >= 16 && a.Hl < 32768 && a.Wl < 32768 &&
          (!a.out_up || (((a.Ho | a.Wo) & 1) == 0 && (a.up_c0 & 63) == 0 && a.up_c0 <= a.Cout)) &&
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
@@ -777,6 +784,13 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   // (layer1 89 vs 93 us, layer2 73 vs 77)
   static const bool force4 = dbg_flag("UWM_F16X3_4WAVE"), force8 = dbg_flag("UWM_F16X3_8WAVE");
   const long wgs = (long)a.N * tilesH * tilesW * tilesN;
+  if (a.Ctot == 16) {                                     // one chunk, 16 outputs: the single-chunk form
+    const size_t lds1 = (size_t)kFBuf * sizeof(_Float16);          // one patch buffer (25 920 B) >= the epilogue's 4 x 64 x 20 floats
+    static DevOnce lds_attr1;
+    { hipError_t e = lds_attr1.set_max_lds((const void*)conv_f16x3_kernel<1>, lds1); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<1>), dim3((unsigned)(a.N * tilesH * tilesW)), dim3(256), lds1, st, a);
+    return hipGetLastError();
+  }
   const bool four = variant == 1 || variant == 3 || (variant != 2 && (force4 || (!force8 && wgs >= 2L * device_cu_count())));
   if (variant == 3 && a.out_up) return hipErrorInvalidValue;
   // 32-channel tiles: no padded fragments on the 32-output layers.  (Also tried for launches whose 64-channel tiles cannot give every

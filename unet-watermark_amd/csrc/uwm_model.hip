@@ -57,9 +57,9 @@ struct ConvL {
   bool x3_d() const { return wino_d() && (CoutP & 15) == 0; }
   // fp16x3 direct form (conv_f16x3.hip): chunk pairs of 16 channels on either side of the concat
   // (Cout >= 32: the 16-output full-resolution layers have their own kernels — conv_up2 / conv_patch16 — which the 64-channel tile
-  // of conv_f16x3 cannot match: 565 vs 176 us on decoder block 4 conv1)
-  bool f3() const { return wino() && (CinP & 31) == 0 && (c0 & 15) == 0 && Cout >= 32; }
-  bool f3_d() const { return wino_d() && (CoutP & 31) == 0 && CinP >= 16; }
+  // of conv_f16x3 cannot match: 565 vs 176 us on decoder block 4 conv1 — except the single-chunk 16 -> 16 form, decoder block 4 conv2, forward and dgrad)
+  bool f3() const { return wino() && (((CinP & 31) == 0 && (c0 & 15) == 0 && Cout >= 32) || (CinP == 16 && c0 == 16 && Cout == 16)); }
+  bool f3_d() const { return wino_d() && (((CoutP & 31) == 0 && CinP >= 16) || (CoutP == 16 && CinP == 16 && Cout == 16)); }
 };
 // encoder residual block.  BasicBlock: c1 3x3(stride) -> c2 3x3, c3 = -1.  Bottleneck: c1 1x1 -> c2 3x3(stride) -> c3 1x1(x4).
 struct BlockL { int c1, c2, cd, c3 = -1, stride = 1, Cin = 0, Cout = 0; int last() const { return c3 >= 0 ? c3 : c2; } };
@@ -1542,7 +1542,7 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st, bool x3 = fa
 // fp16x3 bank for the op-level entry point (tests / timing): cfg 600
 static int op_f16x3_prepare(ConvArgs& a, hipStream_t st) {
   static float* buf = nullptr; static size_t cap = 0;
-  if (a.Ctot & 31) return fail("uwm_op_conv: cfg 600 (fp16x3) needs channels %% 32 == 0");
+  if ((a.Ctot & 31) && !(a.Ctot == 16 && a.Cout <= 16)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs channels %% 32 == 0 (or the 16 -> 16 single-chunk layer)");
   const size_t need = f16x3_bank_floats(a.wrows, a.Ctot);
   if (need > cap) {
     HIPCHK(hipDeviceSynchronize());
