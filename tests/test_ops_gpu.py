@@ -764,6 +764,14 @@ def test_conv_f16x3_direct(cuda, shape):
     _conv_case(cuda, n, cin, 32, h, w, 3, 1, 1, cfg=603, seed=9)
 
 
+def test_conv_stem_f16x3(cuda):
+    """conv_stem_f16x3.hip (cfg 610): the 7x7 / stride-2 / pad-3 stem (3 input channels stored as 4) with one MFMA k-step per kernel
+    row, fp16x3 products: the fp32 bars of _conv_case (output 2e-5 of its range, BatchNorm statistics), whole and partial tiles,
+    odd image sizes."""
+    for n, h, w in ((2, 64, 64), (1, 96, 80), (3, 38, 50), (1, 33, 47)):
+        _conv_case(cuda, n, 3, 64, h, w, 7, 2, 3, cfg=610, seed=h)
+
+
 def test_conv_f16x3_single_chunk_16_to_16(cuda):
     """the single-chunk form of conv_f16x3 (16 -> 16 channels: decoder block 4 conv2), plain and with a lazy BatchNorm + ReLU input,
     whole and partial 16x16 tiles."""

@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 2)) void conv_f16x3_kernel(cons
     for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
     if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
   }
-  // Two register sets of raw patch values (chunks c+1 and c+2 in flight while chunk c is multiplied) and ONE set of lazy-transform
-  // coefficients (those of the chunk being stored).  The store side is branch-free and cut into rounds, so that a round's
+  // ONE register set of raw patch values (a round's register is re-loaded for chunk c+2 right after its chunk-c+1 contents have been
+  // stored) and one set of lazy-transform coefficients (those of the chunk being stored).  The store side is branch-free and cut into rounds, so that a round's
   // conversion work (about 30 VALU instructions + 2 LDS stores) can sit in the shadow of a tap pair's MFMAs — the matrix pipe
   // and the VALU do not co-execute across waves here (PMC: SQ_VALU_MFMA_COEXEC_CYCLES = 6 % of the MFMA-busy cycles with the
   // staging as a phase of its own; 2.8 VALU instructions per MFMA, i.e. 70 % of the MFMA time again, back to back)
@@ -794,7 +794,7 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   const bool four = variant == 1 || variant == 3 || (variant != 2 && (force4 || (!force8 && wgs >= 2L * device_cu_count())));
   if (variant == 3 && a.out_up) return hipErrorInvalidValue;
   // 32-channel tiles: no padded fragments on the 32-output layers.  (Also tried for launches whose 64-channel tiles cannot give every
-  // CU a workgroup — layer4 at batch 16, 128 -> 256 workgroups: 94 vs 105 us alone, but 1050 vs 1052 img/s in the step: not taken.)
+  // CU a workgroup — layer4 at batch 16, 128 -> 256 workgroups: 94 vs 105 us alone, but 1067 vs 1074 img/s in the step: not taken.)
   const bool narrow = !a.out_up && a.Cout <= 32 && four;
   if (variant == 3 || (variant == 0 && narrow)) {
     static DevOnce lds_attr2;

@@ -836,7 +836,7 @@ const char* prof_class_name(int cls) {
       "wgrad_head_kernel",              "conv_up2_kernel",                "conv_up2_dgrad_kernel",
       "wgrad_up2_kernel",               "conv_gemm_kernel<128>",          "conv_gemm_kernel<64>",
       "wgrad_gemm_kernel<128>",         "wgrad_gemm_kernel<64>",          "wgrad_stem_kernel",
-      "conv_f16x3_kernel",              "wgrad_f16x3_kernel"};
+      "conv_f16x3_kernel",              "wgrad_f16x3_kernel",             "conv_stem_f16x3_kernel"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

@@ -128,7 +128,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 44 };   // 43 = wgrad_f16x3 ; 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 45 };   // 44 = conv_stem_f16x3 ; 43 = wgrad_f16x3 ; 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
@@ -207,6 +207,11 @@ size_t f16x3_bank_floats(int rows, int chans);             // bank size in float
 size_t f16x3_rinv_off(int rows, int chans);                 // float offset of that array in the bank
 hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st);
 bool conv_f16x3_applicable(const ConvArgs& a);
+// conv_stem_f16x3.hip: the 7x7 / stride-2 ResNet stem on the fp16x3 arithmetic (one MFMA k-step per kernel row); a.wu = its bank
+size_t stem_f16x3_bank_floats();
+hipError_t launch_stem_f16x3_weights(const float* w, int Kpad, int cin_p, float* bank, hipStream_t st);
+bool conv_stem_f16x3_applicable(const ConvArgs& a);
+hipError_t launch_conv_stem_f16x3(const ConvArgs& a, hipStream_t st);
 hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant = 0);      // variant: 0 auto | 1 four-wave kernel | 2 eight-wave kernel | 3 four-wave, 32-channel tiles (tests)
 bool conv_wino_x3_applicable(const ConvArgs& a);
 hipError_t launch_conv_wino_x3(const ConvArgs& a, hipStream_t st);

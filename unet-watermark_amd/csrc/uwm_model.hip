@@ -59,6 +59,8 @@ struct ConvL {
   // (Cout >= 32: the 16-output full-resolution layers have their own kernels — conv_up2 / conv_patch16 — which the 64-channel tile
   // of conv_f16x3 cannot match: 565 vs 176 us on decoder block 4 conv1 — except the single-chunk 16 -> 16 form, decoder block 4 conv2, forward and dgrad)
   bool f3() const { return wino() && (((CinP & 31) == 0 && (c0 & 15) == 0 && Cout >= 32) || (CinP == 16 && c0 == 16 && Cout == 16)); }
+  // the 7x7 / stride-2 stem of the ResNet encoders (3 input channels stored as 4): conv_stem_f16x3.hip in the fp16x3 modes
+  bool stem7() const { return k == 7 && stride == 2 && pad == 3 && CinP == 4 && Cout == 64 && CoutP == 64 && !dw; }
   bool f3_d() const { return wino_d() && (((CoutP & 31) == 0 && CinP >= 16) || (CoutP == 16 && CinP == 16 && Cout == 16)); }
 };
 // encoder residual block.  BasicBlock: c1 3x3(stride) -> c2 3x3, c3 = -1.  Bottleneck: c1 1x1 -> c2 3x3(stride) -> c3 1x1(x4).
@@ -324,6 +326,7 @@ static int build_model(uwm_model* m) {
   for (auto& c : m->convs) {
     // (one slot per direction holds whichever bank the precision mode asks for: fp32 Winograd, bf16x3 Winograd or fp16x3 direct)
     if (c.wino()) { c.wu_off = f; f += std::max(wino_weights_floats(c.Cout, c.CinP), c.f3() ? f16x3_bank_floats(c.Cout, c.CinP) : 0); f = (size_t)rup((long long)f, 64); }
+    if (c.stem7()) { c.wu_off = f; f += stem_f16x3_bank_floats(); f = (size_t)rup((long long)f, 64); }
     if (c.wino_d()) { c.wud_off = f; f += std::max(wino_weights_floats(c.CinP, c.CoutP), c.f3_d() ? f16x3_bank_floats(c.CinP, c.CoutP) : 0); f = (size_t)rup((long long)f, 64); }
   }
   m->fixed_floats = f;
@@ -501,6 +504,14 @@ static bool f3_fwd_on(const uwm_model* m, size_t ci) {
 }
 // a decoder conv1's dgrad splits the concat gradient in its epilogue (ConvArgs::out_up): the fp16x3 kernel takes it when the
 // boundary sits on a 64-channel tile
+// the stem on conv_stem_f16x3: fp16x3 forward modes, the same fill rule over its 16x16-pixel workgroups
+static bool stem_f3_on(const uwm_model* m) {
+  if (m->stem < 0) return false;
+  const ConvL& cv = m->convs[m->stem]; const Plan& p = m->plan;
+  if (p.prec < UWM_PREC_F16X3 || !cv.stem7() || !cv.wu_off || p.wino_mode == 0 || dbg_flag("UWM_NO_STEM_F16X3")) return false;
+  const long wgs = (long)p.N * ((p.oh[m->stem] + 15) / 16) * ((p.ow[m->stem] + 15) / 16);
+  return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
+}
 static bool f3d_plain(const uwm_model* m, int ci) {
   for (auto& d : m->dec) if (d.c1 == ci) return (d.C0 & 63) == 0;
   for (auto& nd : m->nodes) if (nd.c1 == ci) return (nd.C0 & 63) == 0;
@@ -554,7 +565,12 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
   a.bytes = 4.0 * ((double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) + (double)cv.Cout * cv.Kpad +
                    (double)a.M * cv.CoutP);
-  if (cv.wu_off && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) {
+  if (ci == c.m->stem && cfg < 0 && stem_f3_on(c.m)) {
+    a.wu = c.F(cv.wu_off);
+    if (conv_stem_f16x3_applicable(a)) return launch_conv_stem_f16x3(a, c.st);
+    a.wu = nullptr;
+  }
+  if (cv.wu_off && !cv.stem7() && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) {
     a.wu = c.F(cv.wu_off); a.wu_ncb = wino_ncb(cv.Cout);
     if (c.m->plan.prec == UWM_PREC_BF16X3_ALL && cv.x3()) {
       if (a.C0 != cv.c0 && a.C0 != a.Ctot) return hipErrorInvalidValue;       // the bank was split for this concat boundary
@@ -718,7 +734,7 @@ static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
     auto flush = [&]() { hipError_t e = x3 == 2 ? launch_f16x3_weights_multi(jobs, st) : (x3 ? launch_wino_weights_x3_multi(jobs, st) : launch_wino_weights_multi(jobs, st)); jobs.n = 0; return e; };
     for (size_t ci = 0; ci < m->convs.size(); ++ci) {
       const ConvL& cv = m->convs[ci];
-      if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off)) continue;
+      if (!m->plan.wino_ok(ci) || !(dgrad ? cv.wud_off : cv.wu_off) || cv.stem7()) continue;      // (the stem's slot holds conv_stem_f16x3's bank, built by its own kernel)
       int kind = 0;
       if (dgrad) { if (bf && cv.x3_d()) kind = 1; if (f3_dgrad_on(m, ci)) kind = 2; }
       else { if (prec == UWM_PREC_BF16X3_ALL && cv.x3()) kind = 1; if (f3_fwd_on(m, ci)) kind = 2; }
@@ -762,6 +778,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     m->packed_in_fwd = true; m->pack_mode = p.wino_mode * 8 + p.prec;
   }
   LCHK(wino_jobs(c, false, st));
+  if (stem_f3_on(m)) { const ConvL& sv = m->convs[m->stem]; LCHK(launch_stem_f16x3_weights(m->params + sv.w_off, sv.Kpad, sv.CinP, c.F(sv.wu_off), st)); }
   LCHK(launch_nchw_to_nhwc4(x, c.F(p.x4), N, m->desc.in_channels, H, W, m->CinP, st));
   // eval: all BN scale/shift come from running stats and are known up front
   if (!training) for (size_t i = 0; i < m->bns.size(); ++i) LCHK(run_bn_finalize(c, (int)i, 1, 0));
@@ -1653,6 +1670,15 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
   a.out = y; a.bias = bias;
   if (stats) { a.ssum = stats; a.ssq = stats + Cout; }
   a.dv_ctot = make_fastdiv(a.Ctot); a.dv_kw = make_fastdiv(a.kw);
+  if (cfg == 610) {                                     // the ResNet stem on conv_stem_f16x3.hip
+    static float* sbuf = nullptr;
+    if (!sbuf) HIPCHK(hipMalloc((void**)&sbuf, stem_f16x3_bank_floats() * sizeof(float)));
+    if (kh != 7 || kw != 7 || a.Ctot != 4 || wrows != 64) return fail("uwm_op_conv: cfg 610 is the 7x7 stem (4 stored input channels, 64 outputs)");
+    LCHK(launch_stem_f16x3_weights(w, Kpad, a.Ctot, sbuf, (hipStream_t)stream));
+    a.wu = sbuf;
+    LCHK(launch_conv_stem_f16x3(a, (hipStream_t)stream));
+    return 0;
+  }
   if (cfg >= 600 && cfg <= 603) {                     // 600 auto | 601 four-wave kernel | 602 eight-wave kernel | 603 four-wave, 32-channel tiles
     if (!op_wino_shape(a, kh, kw, stride, pad)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs 3x3 s1 p1, Ho >= 8, Wo >= 16");
     if (op_f16x3_prepare(a, (hipStream_t)stream)) return 1;
