@@ -123,6 +123,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   int prec;                  // 2: fp16x3 direct weight gradient (wgrad_f16x3.hip) where applicable; 0: fp32 kernels
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|dy| (written by bn_bwd_apply): dY is staged times the power of two that puts it in [2^13, 2^14)
   ReduceQueue* rq;           // HOST pointer (never read on the device) or nullptr: queue the partial-sum reduce instead of launching it
+  int cu_share;              // prec 2: 0 = one workgroup per CU; n = per n/4 of the CUs (3 when the launch runs beside the dependent chain: the rest stay free of its 768-thread workgroups)
 };
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on

@@ -643,7 +643,7 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
                    (double)cv.Cout * cv.Kpad);
   a.wino = c.m->plan.wino_mode + 1;
-  if (f3_wgrad_on(c.m, (size_t)ci)) { a.prec = 2; a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off()); }
+  if (f3_wgrad_on(c.m, (size_t)ci)) { a.prec = 2; a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off()); a.cu_share = (c.wst && c.wst != c.st) ? 3 : 0; }
   // partial images of a split launch: the next free slice of the scratch; their reduce is queued and runs with the other layers'
   // in one launch (flush_reduces: when the scratch / queue fills up and at the end of every backward stage)
   static const bool no_defer = dbg_flag("UWM_NO_DEFER_REDUCE");

@@ -294,7 +294,11 @@ hipError_t launch_wgrad_f16x3(const WgradArgs& a0, hipStream_t st) {
   const int pairs = ((a.wrows + 63) / 64) * (a.Ctot / 32);
   const int nstages = a.N * (a.Ho / (128 / wx)) * (a.Wo / wx);
   // one 768-thread workgroup per CU; at least 4 stages per split (the two-stage prefetch needs a few to pay)
-  const int cus = device_cu_count();
+  // one 768-thread workgroup holds a CU's registers almost alone (3 x 138 of 512 per SIMD): beside the dependent chain of the
+  // backward — whose HBM-bound BatchNorm pass then gets one wave per SIMD instead of six — the launch is sized for 3/4 of the
+  // CUs (a.cu_share = 3; measured 1051 -> 1066 img/s; 7/8: 1065, 1/2: 1052)
+  static const int cu_cap = dbg_int("UWM_WG16_CUS", 0);
+  const int cus = cu_cap > 0 ? cu_cap : (a.cu_share > 0 ? device_cu_count() * a.cu_share / 4 : device_cu_count());
   int nsplit = (cus + pairs - 1) / pairs;
   if (nsplit > nstages / 4) nsplit = nstages / 4;
   if (nsplit < 1) nsplit = 1;
