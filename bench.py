@@ -453,7 +453,15 @@ def main():
                                "note": f"profiles/pmc_traffic.json was measured on kernel sources {pm.get('source_sha256')} "
                                        f"(git {pm.get('git_sha')}), this run is {sha}: not quoted"}
                 else:
-                    e_ = pm["kernels"].get(dom["kernel"])
+                    # a profiler class may lump template instances / variants that rocprof names separately (conv_f16x3_kernel<4>, <2>,
+                    # <1>, conv_f16x3s_kernel): launch-weighted average over them
+                    k_ = dom["kernel"]
+                    es_ = [v for n_, v in pm["kernels"].items() if n_ == k_ or n_.startswith(k_ + "<") or (k_ == "conv_f16x3_kernel" and n_ == "conv_f16x3s_kernel")]
+                    e_ = None
+                    if es_:
+                        wsum = sum(max(1, v.get("launches", 1)) for v in es_)
+                        e_ = {f_: int(sum(v[f_] * max(1, v.get("launches", 1)) for v in es_) / wsum)
+                              for f_ in ("hbm_bytes_per_launch", "fetch_bytes_per_launch", "write_bytes_per_launch")}
                     if e_:
                         hb = e_["hbm_bytes_per_launch"]
                         traffic = {"hbm_bytes_per_launch": hb, "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],

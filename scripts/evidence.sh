@@ -16,6 +16,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 cp gpurun_out/${T}_stats/*kernel_stats.csv gpurun_out/${T}_bench_kernel_stats.csv 2>/dev/null || cp gpurun_out/${T}_stats/*/*kernel_stats.csv gpurun_out/${T}_bench_kernel_stats.csv
 UWM_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats_serial -o s -- python3 bench.py --steps 10 --warmup 3 $B > gpurun_out/${T}_stats_serial.log 2>&1
 cp gpurun_out/${T}_stats_serial/*kernel_stats.csv gpurun_out/${T}_bench_serial_kernel_stats.csv 2>/dev/null || cp gpurun_out/${T}_stats_serial/*/*kernel_stats.csv gpurun_out/${T}_bench_serial_kernel_stats.csv
+python3 scripts/launch_list.py gpurun_out/${T}_stats_serial > gpurun_out/${T}_launch_list.txt 2>&1 || true
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_fetch/x -o p -- python3 bench.py --steps 3 --warmup 1 $B > gpurun_out/${T}_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_write/x -o p -- python3 bench.py --steps 3 --warmup 1 $B > gpurun_out/${T}_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/${T}_mfma/x -o p -- python3 bench.py --steps 3 --warmup 1 $B > gpurun_out/${T}_mfma.log 2>&1

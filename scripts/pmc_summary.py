@@ -32,7 +32,7 @@ for k in sorted(dur, key=lambda k: -dur[k])[:16]:
     rows.append(dict(kernel=k, launches=cnt[k], avg_us=round(dur[k] / cnt[k], 1), fetch_bytes_raw=int(fe), fetch_bytes_x2=int(2 * fe),
                      write_bytes=int(wr), mfma_busy_frac=round(busy / (gui / 8 * 1024), 3) if gui else None,
                      clock_GHz=round(gui / 8 / (dur[k] * 1e3), 2) if dur[k] else None))
-    traffic[alias.get(k, k)] = {"hbm_bytes_per_launch": int(2 * fe + wr), "fetch_bytes_per_launch": int(2 * fe), "write_bytes_per_launch": int(wr)}
+    traffic[alias.get(k, k)] = {"hbm_bytes_per_launch": int(2 * fe + wr), "fetch_bytes_per_launch": int(2 * fe), "write_bytes_per_launch": int(wr), "launches": cnt[k]}
 json.dump(rows, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 json.dump({"source": f"profiles/{tag}_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; FETCH_SIZE x2 (gfx950), per launch",
            "source_sha256": source_sha256(),          # the kernel sources these counters were measured on (bench.py refuses another)
