@@ -12,7 +12,7 @@ python -c "import sys; sys.path.insert(0,'.'); import __graft_entry__ as g; g.bu
 src=conv_f16x3; def=UWM_F16_ABL; tag=f16
 if [ "$1" = wgrad ]; then src=wgrad_f16x3; def=UWM_WG16_ABL; tag=wg16; shift; fi
 for b in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -D$def=$b -c unet-watermark_amd/csrc/$src.hip -o unet-watermark_amd/abl/${src}_$b.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops -D$def=$b -c unet-watermark_amd/csrc/$src.hip -o unet-watermark_amd/abl/${src}_$b.o
   objs=$(ls unet-watermark_amd/build/*.o | grep -v /$src.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o unet-watermark_amd/abl/libuwm_${tag}_$b.so $objs unet-watermark_amd/abl/${src}_$b.o
 done

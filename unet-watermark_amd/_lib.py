@@ -20,6 +20,13 @@ _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
 SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "conv_wino_x3.hip", "conv_f16x3.hip", "conv_stem_f16x3.hip", "conv_up2.hip", "conv_gemm.hip", "conv_head.hip", "mbconv.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "wgrad_f16x3.hip", "wgrad_c16.hip", "wgrad_gemm.hip", "wgrad_stem.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
+# per-file compiler flags.  The fp16x3 kernels interleave their staging VALU work with MFMAs; hipcc turns the f4 arithmetic of that
+# work into packed v_pk_{fma,mul,add}_f32, which cost more than two plain VALU instructions beside MFMAs (MI355X_MICROARCH.md,
+# "packed f32 VALU ... an anti-lever beside MFMAs").  Without them: 1099 -> 1110 img/s on the headline step (same box, alternating
+# runs); the exact-fp32 kernels measured the other way (782 vs 779) and keep the default.  (The host pass of hipcc ignores the
+# feature with a warning.)
+EXTRA_FLAGS = {name: ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+               for name in ("conv_f16x3.hip", "wgrad_f16x3.hip", "conv_stem_f16x3.hip")}
 
 
 class uwm_unet_desc(C.Structure):
@@ -124,7 +131,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     procs = []
     for s in srcs:
         o = objdir / (s.stem + ".o")
-        cmd = [hipcc, f"--offload-arch={HIP_ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(s), "-o", str(o)]
+        cmd = [hipcc, f"--offload-arch={HIP_ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(s.name, []) + ["-c", str(s), "-o", str(o)]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), o))
     objs = []
     for cmd, p, o in procs:

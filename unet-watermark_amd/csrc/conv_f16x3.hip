@@ -208,7 +208,7 @@ __device__ __forceinline__ void f16x3_split_epilogue(const ConvArgs& a, const fl
 }
 
 // ---------------------------------------------------------------- main kernel
-__device__ __forceinline__ float clamp_h(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }      // (one v_med3_f32; fminf(fmaxf()) adds a canonicalising v_max per value)
 
 // NJ = 16-channel fragments per workgroup: 4 (64 output channels) or 2 (32: the 32-output layers of decoder block 3 — half of a
 // 64-channel tile's MFMAs and filter loads were padding there: 400 / 162 us forward against 416 / 152 on the fp32 Winograd kernel)

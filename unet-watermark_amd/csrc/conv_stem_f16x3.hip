@@ -74,7 +74,7 @@ hipError_t launch_stem_f16x3_weights(const float* w, int Kpad, int cin_p, float*
   return hipGetLastError();
 }
 
-__device__ __forceinline__ float clamp_hs(float v) { return fminf(fmaxf(v, -65504.f), 65504.f); }
+__device__ __forceinline__ float clamp_hs(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 
 __global__ __launch_bounds__(256, 2) void conv_stem_f16x3_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 ssm[];      // [hi | lo][37][40][4]; the epilogue's [4][64][68] floats alias it
