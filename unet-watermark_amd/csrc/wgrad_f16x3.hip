@@ -32,7 +32,7 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
 
 #ifndef UWM_WG16_ABL
-#define UWM_WG16_ABL 0      // compile-time timing ablations (scripts/ablate_f16x3.sh wgrad ...): 1 no MFMA, 2 no X fragment reads, 4 no loader work after the first stage; 0 in the product build
+#define UWM_WG16_ABL 0      // compile-time timing ablations (scripts/ablate_f16x3.sh wgrad ...): 1 no MFMA, 2 no X fragment reads, 4 no loader work after the first stage, 8 no partial-image stores; 0 in the product build
 #endif
 // Stage geometry: 128 pixels = kWR rows x WX pixels (WX = 32: 4 x 32, one image row per 32-pixel k-step; WX = 16, the 16-pixel-wide
 // maps of the deepest encoder stage: 8 x 16, two image rows per k-step).  Halo patch (kWR + 2) x (WX + 2).
@@ -258,7 +258,8 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
           if (row < a.wrows && ci < a.Ctot) {
             float* pd = dst + (size_t)row * a.Kpad + t * a.Ctot + ci;
             const float v = acc[cf][t][e] * ixs;
-            if (a.nsplit > 1) *pd = v; else *pd += v;
+            if (UWM_WG16_ABL & 8) { if (v == 123.456f) *pd = v; }      // (timing ablation: no partial-image stores)
+            else if (a.nsplit > 1) *pd = v; else *pd += v;
           }
         }
   }
