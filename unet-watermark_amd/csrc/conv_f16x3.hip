@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) void f16x3_rowmax_kernel(const WinoJobs jobs) 
     const int row = blockIdx.x * 4 + wv;
     if (row >= jb.rows) return;
     float mx = 0.f;
-    const float* wr = jb.w + (size_t)row * jb.Kpad;
-    for (int i = z * 64 + lane; i < K; i += nz * 64) mx = fmaxf(mx, fabsf(wr[i]));
+    const f4* wr = (const f4*)(jb.w + (size_t)row * jb.Kpad);      // (K = 9 * chans, chans % 16 == 0; rows are 128-byte aligned)
+    for (int i = z * 64 + lane; i < K / 4; i += nz * 64) {
+      const f4 v = wr[i];
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
     if (lane == 0 && mx > 0.f) atomicMax(rmax + row, __float_as_uint(mx));
@@ -793,9 +796,11 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   }
   const bool four = variant == 1 || variant == 3 || (variant != 2 && (force4 || (!force8 && wgs >= 2L * device_cu_count())));
   if (variant == 3 && a.out_up) return hipErrorInvalidValue;
-  // 32-channel tiles: no padded fragments on the 32-output layers.  (Also tried for launches whose 64-channel tiles cannot give every
-  // CU a workgroup — layer4 at batch 16, 128 -> 256 workgroups: 94 vs 105 us alone, but 1067 vs 1074 img/s in the step: not taken.)
-  const bool narrow = !a.out_up && a.Cout <= 32 && four;
+  // 32-channel tiles: no padded fragments on the 32-output layers — and, in the FORWARD pass only, twice the workgroups where
+  // 64-channel tiles cannot give every CU one (layer4 at batch 16: 128 -> 256 workgroups, 94 vs 105 us; in the backward the idle
+  // CUs of such a launch are not idle — the weight-gradient stream runs there — and the narrow tiles measured 1067 vs 1074 img/s)
+  const bool fwd_alone = a.rmul == 1 && !a.xmax;
+  const bool narrow = !a.out_up && (a.Cout <= 32 ? four : (fwd_alone && variant == 0 && wgs < device_cu_count()));
   if (variant == 3 || (variant == 0 && narrow)) {
     static DevOnce lds_attr2;
     { hipError_t e = lds_attr2.set_max_lds((const void*)conv_f16x3_kernel<2>, lds); if (e != hipSuccess) return e; }
