@@ -20,7 +20,7 @@ def timeit(f, reps=20):
 
 
 for name, cin, cout, h in (("layer1", 64, 64, 128), ("layer2", 128, 128, 64), ("layer3", 256, 256, 32), ("dec2.c2", 64, 64, 128),
-                           ("dec1.c1", 384, 128, 64), ("dec0.c1", 768, 256, 32)):
+                           ("dec1.c1", 384, 128, 64), ("dec0.c1", 768, 256, 32), ("dec3.c1", 128, 32, 256), ("dec3.c2", 32, 32, 256)):
     x = torch.randn(N, h, h, cin, device=dev); dy = torch.randn(N, h, h, cout, device=dev) * 1e-5
     kpad = rup(9 * cin, 32)
     dw = torch.zeros(cout, kpad, device=dev)
