@@ -557,36 +557,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// the same reduce for every job of a queue in one launch: a workgroup finds its job by its block range
+// the same reduce for every job of a queue in one launch: a workgroup finds its job by its block range.  A thread owns ONE 16-byte
+// unit of dW and walks all the split images itself, eight loads in flight (a workgroup reads 4 KB contiguous per split: the
+// 8-group / 512-byte form above ran at 2 TB/s on the step's 0.7 GB of partial images); the order of the additions depends on
+// nsplit alone: bit-reproducible
+constexpr int kRedUnits = 256;                 // 16-byte units of dW per workgroup
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceJobs jobs) {
-  __shared__ f4 red[8][32];
   int k = 0;
   while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].block0) ++k;
   const float* __restrict__ part = jobs.j[k].part; float* __restrict__ dw = jobs.j[k].dw;
   const size_t n4 = jobs.j[k].n4; const int nsplit = jobs.j[k].nsplit;
-  const int u = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const size_t i = (size_t)(blockIdx.x - jobs.j[k].block0) * 32 + u;
+  const size_t i = (size_t)(blockIdx.x - jobs.j[k].block0) * kRedUnits + threadIdx.x;
+  if (i >= n4) return;
+  const float* __restrict__ p0 = part + i * 4;
+  const size_t st = n4 * 4;
   f4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i < n4) {
-    // four loads in flight per thread (a serial chain of nsplit / 8 dependent 16-byte loads ran at 1.7 TB/s); the order of the
-    // additions is fixed by (nsplit, grp) alone: bit-reproducible
-    const float* __restrict__ p0 = part + i * 4;
-    int q = grp;
-    for (; q + 24 < nsplit; q += 32) {
-      const f4 a0 = *(const f4*)(p0 + (size_t)q * n4 * 4), a1 = *(const f4*)(p0 + (size_t)(q + 8) * n4 * 4);
-      const f4 a2 = *(const f4*)(p0 + (size_t)(q + 16) * n4 * 4), a3 = *(const f4*)(p0 + (size_t)(q + 24) * n4 * 4);
-      s += (a0 + a1) + (a2 + a3);
-    }
-    for (; q < nsplit; q += 8) s += *(const f4*)(p0 + (size_t)q * n4 * 4);
+  int q = 0;
+  for (; q + 8 <= nsplit; q += 8) {
+    const f4 a0 = *(const f4*)(p0 + (size_t)q * st), a1 = *(const f4*)(p0 + (size_t)(q + 1) * st);
+    const f4 a2 = *(const f4*)(p0 + (size_t)(q + 2) * st), a3 = *(const f4*)(p0 + (size_t)(q + 3) * st);
+    const f4 a4 = *(const f4*)(p0 + (size_t)(q + 4) * st), a5 = *(const f4*)(p0 + (size_t)(q + 5) * st);
+    const f4 a6 = *(const f4*)(p0 + (size_t)(q + 6) * st), a7 = *(const f4*)(p0 + (size_t)(q + 7) * st);
+    s += ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
   }
-  red[grp][u] = s;
-  __syncthreads();
-  if (grp == 0 && i < n4) {
-    f4 t = red[0][u];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) t += red[g][u];
-    *(f4*)(dw + i * 4) += t;
-  }
+  for (; q < nsplit; ++q) s += *(const f4*)(p0 + (size_t)q * st);
+  *(f4*)(dw + i * 4) += s;
 }
 
 hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* dw, hipStream_t st, ReduceQueue* rq) {      // shared with wgrad_gemm.hip
@@ -594,7 +589,7 @@ hipError_t launch_wgrad_reduce(const float* part, int nsplit, size_t n4, float* 
     if (rq->n >= ReduceQueue::kMax) return hipErrorInvalidValue;       // the owner flushes before the queue is full
     ReduceJob& j = rq->j[rq->n++];
     j.part = part; j.dw = dw; j.n4 = n4; j.nsplit = nsplit; j.block0 = rq->blocks;
-    rq->blocks += (unsigned)((n4 + 31) / 32);
+    rq->blocks += (unsigned)((n4 + kRedUnits - 1) / kRedUnits);
     rq->used_floats += ((size_t)nsplit * n4 * 4 + 63) & ~(size_t)63;
     return hipSuccess;
   }
