@@ -11,8 +11,8 @@ hot lines of /root/reference/src/train.py:86-105 — on configs[1] of BASELINE.j
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP event pairs attached to every conv / wgrad
 dispatch (hipExtLaunchKernelGGL, on the stream the kernel is launched on) during the timed region (uwm_prof_*);
-`roofline.frac` is EXECUTED MFMA FLOP/s over the fp32-MFMA peak (the Winograd kernels' algorithmic rate is a separate
-field); `cpu_baseline` times
+`roofline.frac` is ALGORITHMIC conv FLOP/s of the dominant kernel class over the dense peak of the matrix instruction it
+issues (`roofline.mfma_util` = the FLOPs the pipe executed, 3x for the fp16x3 split products); `cpu_baseline` times
 the CPU oracle (the reference's CPU path restated in plain torch) on this host's cores on a bounded
 sample of the same workload.
 """
@@ -43,7 +43,7 @@ F16X3_DTYPE = ("f32 storage and accumulation; the 3x3 stride-1 convolution produ
 
 
 def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Unet", batch: int = 16, decoder_channels=None,
-                 precision: str = "f32"):
+                 precision: str = "f32", routing_ref=None):
     """Oracle (torch CPU fp32) train step on this host's cores.  `value` is timed at the bench's OWN batch size (SURVEY 8d:
     the identical config-2 step, >= 3 timed steps) when one such step fits the time budget, else on a bs2 sample; the
     parity numbers (mask IoU, logits, loss, gradient cosine) always come from a bs2 sample of the same workload."""
@@ -102,7 +102,10 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
         dev = torch.device("cuda", torch.cuda.current_device())
         ref0 = O.build(encoder, seed=42, arch=arch, **kw)
         hm = getattr(U, arch)(encoder, **kw).to(dev)
-        hm.set_precision(precision)                  # the parity numbers are those of the benched precision mode
+        # the parity numbers are those of the benched precision mode ON THE KERNELS THE BENCHED BATCH TAKES: the sample is 2 images,
+        # the routing batch (uwm_set_routing_batch) makes every size-dependent kernel choice as for `batch` images
+        hm.set_precision(precision, routing_batch=batch)
+        hm.routing(enable=True)
         hm.load_state_dict(ref0.state_dict())
         hm.train(); ref0.train()
         cr, ch = O.DiceLoss(smooth=1e-5), U.DiceLoss(mode="binary", smooth=1e-5)
@@ -121,10 +124,17 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
                 cmin = min(cmin, float(g1 @ g2 / (g1.norm() * g2.norm())))
         out["min_grad_cosine_vs_cpu_ref"] = round(cmin, 6)
         out["parity_precision_mode"] = precision
+        rt = hm.routing()
+        kinds = {}
+        for pas, _layer, kern in rt:
+            kinds[f"{pas}:{kern}"] = kinds.get(f"{pas}:{kern}", 0) + 1
+        out["parity_sample_routing"] = {"routing_batch": batch, "launches": len(rt), "kernels": dict(sorted(kinds.items())),
+                                        "matches_timed_step": (routing_ref is None or [tuple(r) for r in rt] == [tuple(r) for r in routing_ref])}
+        hm.routing(enable=False)
         # the other precision modes on the same batch / weights / oracle run
         alt = {}
         for mode in [m_ for m_ in ("f32", "f16x3_all", "bf16x3") if m_ != precision]:
-            hm.load_state_dict(ref0.state_dict()); hm.set_precision(mode)
+            hm.load_state_dict(ref0.state_dict()); hm.set_precision(mode, routing_batch=batch)
             for p_ in hm.parameters():
                 p_.grad = None
             o2 = hm(x.to(dev)); l2 = ch(o2, t.unsqueeze(1).to(dev)); l2.backward()
@@ -135,7 +145,7 @@ def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Une
                     c2 = min(c2, float(g1 @ g2 / (g1.norm() * g2.norm())))
             alt[mode] = {"logit_max_abs_err_vs_cpu_ref": float(f"{float((o2.detach().cpu() - lr_).abs().max()):.3e}"),
                          "min_grad_cosine_vs_cpu_ref": round(c2, 6)}
-        hm.set_precision(precision)
+        hm.set_precision(precision, routing_batch=0)
         out["alt_modes_parity"] = alt
     except Exception as e:                      # never let the checker break the bench line
         out["mask_iou_vs_cpu_ref"] = None
@@ -368,6 +378,17 @@ def main():
     L.lib().uwm_prof_enable(0)
     ents = collect_prof(L, prof_steps)
     loss_val = float(loss[0].item())
+    # kernel routing of the benched step (one extra UNTIMED step with the library's routing record on): the parity sample of
+    # cpu_baseline must take the same kernels layer by layer
+    routing_ref = None
+    if rank == 0 and world == 1:
+        model.routing(enable=True)
+        ug = trainer.use_graph
+        trainer.use_graph = False
+        trainer.step(x, t); torch.cuda.synchronize(dev)
+        trainer.use_graph = ug
+        routing_ref = model.routing()
+        model.routing(enable=False)
     # the dominant kernel ALONE (not part of `value`): the same step with the wgrad side stream switched off
     ents_s = None
     if args.serial_steps > 0 and rank == 0 and world == 1:
@@ -439,8 +460,8 @@ def main():
             alone = None
             if ents_s is not None and dom["kernel"] in ents_s:
                 a_ = ents_s[dom["kernel"]]
-                alone = {"avg_launch_us": a_["avg_us"], "achieved": a_["mfma_tflops"], "frac": round(a_["mfma_tflops"] / P, 4),
-                         "algorithmic_tflops": a_["algorithmic_tflops"],
+                alone = {"avg_launch_us": a_["avg_us"], "achieved": a_["algorithmic_tflops"], "frac": round(a_["algorithmic_tflops"] / P, 4),
+                         "mfma_util": round(a_["mfma_tflops"] / P, 4), "mfma_executed_tflops": a_["mfma_tflops"],
                          "note": f"{args.serial_steps} extra untimed steps with the wgrad side stream off (nothing co-resident)"}
             traffic = None
             try:   # HBM bytes per launch from SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
@@ -471,37 +492,38 @@ def main():
             except Exception as e:
                 traffic = {"hbm_bytes_per_launch": None, "note": f"no PMC traffic file: {type(e).__name__}"}
             out["roofline"] = {
-                "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["mfma_tflops"], "peak": P, "unit": "TFLOP/s",
-                "frac": round(dom["mfma_tflops"] / P, 4),
-                "definition": "achieved = FLOPs the MFMA pipe EXECUTED per launch / average launch duration of the kernel with the "
-                              "largest share of kernel time, over the profiled steps of the timed region (dispatch-attached HIP "
-                              "events on the launch stream; co-resident with the other stream's kernels); peak = the dense peak of the "
-                              "matrix instruction THAT kernel issues (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 157.3 TF, "
-                              "v_mfma_f32_16x16x32_f16 2500 TF; an fp16x3 kernel executes 3x its direct-convolution FLOPs there, a Winograd "
-                              "kernel 1/2.25 of them on the fp32 pipe); frac = achieved / peak (never > 1)",
+                "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["algorithmic_tflops"], "peak": P, "unit": "TFLOP/s",
+                "frac": round(dom["algorithmic_tflops"] / P, 4),
+                "mfma_util": round(dom["mfma_tflops"] / P, 4), "mfma_executed_tflops": dom["mfma_tflops"],
+                "definition": "achieved = ALGORITHMIC FLOPs per launch (direct-convolution FLOPs of SURVEY.md 8(d): 2*N*Ho*Wo*Cout*Cin*k*k) "
+                              "/ average launch duration of the kernel class with the largest share of kernel time, over the profiled "
+                              "steps of the timed region (dispatch-attached HIP events on the launch stream; co-resident with the other "
+                              "stream's kernels); peak = the dense peak of the matrix instruction THAT kernel issues "
+                              "(MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 157.3 TF, v_mfma_f32_16x16x32_f16 2500 TF); frac = achieved / "
+                              "peak.  mfma_util = FLOPs the MFMA pipe EXECUTED / the same duration / peak: an fp16x3 kernel executes 3x its "
+                              "algorithmic FLOPs (hi*hi + hi*lo + lo*hi buy fp32-class accuracy on the f16 pipe), a Winograd kernel "
+                              "1/2.25 of them — pipe utilisation, not the roofline fraction",
                 "mfma_pipe": dom["mfma_pipe"],
                 "hbm_view": {"achieved_GBps": dom["algorithmic_GBps"], "peak_GBps": 8000.0, "frac": round(dom["algorithmic_GBps"] / 8000.0, 4),
                              "note": "algorithmic bytes (every operand once + the output once) / the same duration: the fp16x3 kernels are "
                                      "closer to this roof than to their matrix pipe's"},
                 "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
-                "algorithmic": {"tflops": dom["algorithmic_tflops"],
-                                "note": "direct-convolution FLOPs of SURVEY.md 8(d) / the same duration; Winograd F(2x2,3x3) kernels "
-                                        "execute 1/2.25 of them, so this figure is NOT a utilisation"},
                 "alone": alone,
                 # the next kernels by time in the step (the first three are within a few per cent of each other on the headline
                 # config, so which one is "dominant" can flip between runs): same definitions
-                "runners_up": [{"kernel": k["kernel"], "frac": round(k["mfma_tflops"] / k["_peak"], 4), "mfma_pipe": k["mfma_pipe"], "avg_launch_us": k["avg_us"],
+                "runners_up": [{"kernel": k["kernel"], "frac": round(k["algorithmic_tflops"] / k["_peak"], 4), "mfma_util": round(k["mfma_tflops"] / k["_peak"], 4),
+                                "mfma_pipe": k["mfma_pipe"], "avg_launch_us": k["avg_us"],
                                 "launches_per_step": k["launches_per_step"], "ms_per_step": k["ms_per_step"], "hbm_frac": round(k["algorithmic_GBps"] / 8000.0, 4),
-                                "alone_frac": (round(ents_s[k["kernel"]]["mfma_tflops"] / k["_peak"], 4)
+                                "alone_frac": (round(ents_s[k["kernel"]]["algorithmic_tflops"] / k["_peak"], 4)
                                                if ents_s is not None and k["kernel"] in ents_s else None),
                                 "alone_avg_launch_us": (ents_s[k["kernel"]]["avg_us"]
                                                         if ents_s is not None and k["kernel"] in ents_s else None)}
                                for k in kernels[1:3]],
-                "step": {"mfma_tflops": round(tot_ex * 1e-9 / prof_steps / ms_step, 2),
-                         "frac": round(sum(k["_exec"] / k["_peak"] for k in kernels) * 1e-9 / prof_steps / ms_step, 4),
-                         "frac_definition": "sum over conv / wgrad classes of (executed MFMA FLOPs / that class's matrix-pipe peak) / wall "
-                                            "step time: the share of the step the matrix pipes would be busy at their peaks",
-                         "algorithmic_tflops": round(tot_fl * 1e-9 / prof_steps / ms_step, 2),
+                "step": {"algorithmic_tflops": round(tot_fl * 1e-9 / prof_steps / ms_step, 2),
+                         "frac": round(sum(k["_fl"] / k["_peak"] for k in kernels) * 1e-9 / prof_steps / ms_step, 4),
+                         "frac_definition": "sum over conv / wgrad classes of (algorithmic FLOPs / that class's matrix-pipe peak) / wall step time",
+                         "mfma_executed_tflops": round(tot_ex * 1e-9 / prof_steps / ms_step, 2),
+                         "mfma_util": round(sum(k["_exec"] / k["_peak"] for k in kernels) * 1e-9 / prof_steps / ms_step, 4),
                          "conv_kernel_ms_per_step": round(tot_ms / prof_steps, 3),
                          "note": "all conv / wgrad launches of a step: executed MFMA FLOPs / WALL step time (two streams overlap, so "
                                  "kernel ms per step may exceed the step)"},
@@ -511,7 +533,8 @@ def main():
         if alt_modes is not None:
             out["alt_modes"] = alt_modes
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch, batch=n, decoder_channels=dec, precision=args.precision)
+            out["cpu_baseline"] = cpu_baseline(args.encoder, s, arch=args.arch, batch=n, decoder_channels=dec, precision=args.precision,
+                                               routing_ref=routing_ref)
             if alt_modes is not None:
                 for mode, par in out["cpu_baseline"].pop("alt_modes_parity", {}).items():
                     alt_modes[mode]["parity_vs_cpu_ref"] = par

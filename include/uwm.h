@@ -212,6 +212,17 @@ int  uwm_get_precision(uwm_handle h);
  * `min_workgroups` of them (0 = the default: one per two compute units — measured: layer4 at batch 16, 128 workgroups on 256 CUs,
  * is still 2 % of the step faster there than on the fp32 Winograd kernels; smaller launches stay on those, which tile finer).  1 = wherever the shape allows (tests). */
 int  uwm_set_precision_fill(uwm_handle h, int min_workgroups);
+/* Routing batch: with batch > 0 every size-dependent kernel choice (fp16x3 fill rule, 4- / 8-wave and tile-width variants, tile
+ * configurations of the implicit GEMM) is made as if the batch were `batch` images, whatever N uwm_forward gets; grids and split
+ * counts follow the real N.  A 2-image parity sample then runs on exactly the kernels the 16-image step takes (bench.py, tests).
+ * 0 (default) = the real batch. */
+int  uwm_set_routing_batch(uwm_handle h, int batch);
+/* Routing record: while enabled, every convolution-class launch of uwm_forward / uwm_backward appends one line
+ * "<fwd|dgrad|wgrad> <layer name> <kernel>" (launch order) to a per-handle text.  uwm_routing_dump copies it (NUL-terminated, at
+ * most cap bytes) and returns the size the whole text needs including the NUL; clear != 0 empties it afterwards.  Host-side
+ * bookkeeping only: no device work, no effect on results. */
+int  uwm_routing_enable(uwm_handle h, int on);
+long long uwm_routing_dump(uwm_handle h, char* buf, long long cap, int clear);
 /* EfficientNet encoders only: stochastic depth ("drop connect") of the MBConv blocks in training mode.  `rowscale` is a
  * device array [uwm_num_mbconv_blocks][N] holding, per block and sample, keep/(1 - p_block) with keep in {0,1}; the host
  * draws it each step (uwm_mbconv_drop_rate gives p_block; blocks without identity skip ignore their row).  NULL (the

@@ -23,7 +23,9 @@ def _grad_cos_l2(model, ref):
     return worst_cos, worst_l2
 
 
-def test_config2_resnet34_512_bs2_vs_oracle(cuda):
+@pytest.mark.parametrize("mode,fill,route", [("f32", 0, 0), ("f16x3_all", 0, 16), ("f16x3_all", 1, 0)],
+                         ids=["f32", "f16x3_all-bs16routing", "f16x3_all-fill1"])
+def test_config2_resnet34_512_bs2_vs_oracle(cuda, mode, fill, route):
     """The check bench.py's cpu_baseline leg prints next to every perf number (SURVEY 8d "parity checks reported with every
     perf number"), as a test: Unet-resnet34 at the bench resolution, train-mode BatchNorm, identical weights — logits
     <= 1e-3, Dice loss 1e-5, mask IoU, gradient cosine."""
@@ -32,6 +34,9 @@ def test_config2_resnet34_512_bs2_vs_oracle(cuda):
     ref = O.build("resnet34", seed=42)
     m = U.Unet("resnet34").to(cuda)
     m.load_state_dict(ref.state_dict())
+    # exact fp32; the benched mode on the kernels the bs16 step takes (default fill rule, routing batch 16); every eligible layer on fp16x3
+    m.set_precision(mode, min_workgroups=fill, routing_batch=route)
+    m.routing(enable=True)
     m.train(); ref.train()
     x, t = O.synthetic_batch(2, 512, 512, seed=42)
     o_ref = ref(x); l_ref = O.DiceLoss(smooth=1e-5)(o_ref, t.unsqueeze(1)); l_ref.backward()
@@ -43,6 +48,13 @@ def test_config2_resnet34_512_bs2_vs_oracle(cuda):
     assert float((a & b).sum()) / max(1.0, float((a | b).sum())) > 0.9995          # mask IoU vs CPU ref (BASELINE metric)
     cos, l2 = _grad_cos_l2(m, ref)
     assert cos > 0.9995 and l2 < 3e-2, (cos, l2)
+    kinds = {k.split("<")[0] for _, _, k in m.routing()}
+    if mode == "f32":
+        assert not any("f16x3" in k for k in kinds), kinds
+    else:
+        assert {"conv_f16x3_kernel", "wgrad_f16x3_kernel", "conv_stem_f16x3_kernel"} <= kinds, kinds
+        if route == 16:
+            assert "conv_f16x3s_kernel" in kinds, kinds          # layer3 / layer4 at bs16: the eight-wave kernel
 
 
 def test_config4_full_size_effb4_1024_bs4(cuda):
@@ -114,7 +126,8 @@ def test_config4_full_size_effb4_1024_bs4(cuda):
     assert torch.isfinite(full).all()
 
 
-def test_config5_bs64_512_hipgraph(cuda):
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_config5_bs64_512_hipgraph(cuda, prec):
     """BASELINE config 5 at its real size: Unet-resnet34, 64x3x512x512, eval-mode forward captured in a hipGraph and
     replayed (/root/reference/src/predict.py:339-357,610-625 runs batch 1 per image): replay == eager == the batch-1 path
     bit for bit; two images against the oracle's eval forward <= 1e-3; masks by the reference's raw-logit threshold equal
@@ -126,7 +139,7 @@ def test_config5_bs64_512_hipgraph(cuda):
     ref = O.build("resnet34", seed=42)
     m = U.Unet("resnet34").to(cuda)
     m.load_state_dict(ref.state_dict())
-    m.set_precision("f32")            # (as above: bs64 == bs1 bit for bit)
+    m.set_precision(prec, min_workgroups=1 if prec != "f32" else 0)            # (bs64 == bs1 bit for bit: the exact mode, or the fp16x3 forward mode with its fill threshold at 1 — what WatermarkPredictor sets)
     # representative running statistics (a fresh net's 0/1 statistics do not normalise: logits of +-70): a few train-mode
     # forwards on the HIP model, then BOTH models carry those buffers
     xs, _ = O.synthetic_batch(8, 512, 512, seed=5)

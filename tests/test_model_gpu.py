@@ -490,13 +490,41 @@ def test_module_protocol_and_errors(cuda):
     assert not torch.equal(before, m.flat_parameters())
 
 
-def test_full_size_properties_bs16_512(cuda):
-    """BASELINE config 2 shape (resnet34, 16x3x512x512): size-independent properties —
-    finite outputs, gradient linearity in dlogits, and step-to-step determinism of the forward."""
+# kernels the benched f16x3_all step must run on at bs16 / 512^2 under the default fill rule: asserted from the
+# library's routing record, and a bs2 sample with uwm_set_routing_batch(16) must take EXACTLY the same kernels layer by layer
+def _expect_f16x3_headline_routing(routing):
+    by = {}
+    for pas, layer, kern in routing:
+        by.setdefault((pas, layer), []).append(kern)
+    f16_fwd = [k for (p_, l), ks in by.items() if p_ == "fwd" for k in ks if "f16x3" in k]
+    f16_dg = [k for (p_, l), ks in by.items() if p_ == "dgrad" for k in ks if "f16x3" in k]
+    f16_wg = [k for (p_, l), ks in by.items() if p_ == "wgrad" for k in ks if "f16x3" in k]
+    # resnet34 Unet: 36 conv layers of the encoder + 10 of the decoder + head; the 3x3 stride-1 layers with channels % 32 == 0
+    # are 6 + 7 + 11 + 5 encoder convs and 8 decoder convs (dec0..dec3), + the single-chunk dec4.conv2, + the stem
+    assert len(f16_fwd) >= 38, (len(f16_fwd), sorted(set(f16_fwd)))
+    assert len(f16_dg) >= 30, (len(f16_dg), sorted(set(f16_dg)))
+    assert len(f16_wg) >= 30, (len(f16_wg), sorted(set(f16_wg)))
+    for layer in ("encoder.layer1.0.conv1", "encoder.layer2.1.conv2", "encoder.layer3.2.conv1", "encoder.layer4.1.conv1",
+                  "decoder.blocks.0.conv1.0", "decoder.blocks.2.conv2.0"):
+        assert any("conv_f16x3" in k for k in by[("fwd", layer)]), (layer, by[("fwd", layer)])
+        assert any("wgrad_f16x3" in k for k in by[("wgrad", layer)]), (layer, by[("wgrad", layer)])
+    assert any("conv_f16x3" in k for k in by[("dgrad", "encoder.layer1.0.conv2")])
+    assert any("conv_stem_f16x3" in k for k in by[("fwd", "encoder.conv1")])
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3_all"])
+def test_full_size_properties_bs16_512(cuda, mode):
+    """BASELINE config 2 shape (resnet34, 16x3x512x512) in the exact-fp32 mode AND in the mode bench.py times (f16x3_all, default
+    fill rule): size-independent properties — finite outputs, gradient linearity in dlogits, step-to-step determinism of the
+    forward, a falling loss.  In f16x3_all the routing record of this very bs16 step is held against the expected kernels, and a
+    bs2 sample with the routing batch set to 16 must take the same kernels layer by layer and meet the oracle bars
+    (logits 1e-3, loss, mask IoU, gradient cosine): the kernel routing of the headline number, compared with the CPU oracle."""
     import unet_watermark_amd as U
     from unet_watermark_amd.train import Trainer
     torch.manual_seed(0)
     m = U.Unet("resnet34").to(cuda)
+    m.set_precision(mode, min_workgroups=0, routing_batch=0)
+    m.routing(enable=True)
     x = torch.randn(16, 3, 512, 512, device=cuda)
     t = torch.zeros(16, 512, 512, dtype=torch.int64, device=cuda)
     t[:, 100:300, 50:400] = 1
@@ -514,11 +542,49 @@ def test_full_size_properties_bs16_512(cuda):
     assert rel < 1e-4, rel                      # linearity (fp32 atomics reorder only)
     logits2 = m._forward_raw(x, training=True)
     assert (logits2 - logits).abs().max() < 1e-5     # batch statistics via fp64 atomics
+    route16 = m.routing()
+    fwd16 = [r for r in route16 if r[0] == "fwd"]
+    assert len(fwd16) == 2 * 47, len(fwd16)      # two forwards x (36 encoder + 10 decoder + 1 head) convolutions
+    if mode == "f16x3_all":
+        _expect_f16x3_headline_routing(route16)
     tr = Trainer(m, w_dice=1.0, w_bce=0.0, lr=1e-4)
     l0 = tr.step(x, t)[0].item()
     for _ in range(3):
         l1 = tr.step(x, t)[0].item()
     assert l1 < l0                               # the step optimises the Dice loss
+    tr.opt.close()
+    del tr
+    # ---- the same kernels on a sample the CPU oracle finishes in seconds
+    from oracle import unet_oracle as O
+    ref = O.build("resnet34", seed=42)
+    m.load_state_dict(ref.state_dict())
+    m.set_precision(mode, routing_batch=16)
+    xs, ts = O.synthetic_batch(2, 512, 512, seed=42)
+    m.train(); ref.train()
+    m.routing()                                   # (drop the Trainer steps' record)
+    for p_ in m.parameters():
+        p_.grad = None
+    o = m(xs.to(cuda)); l = U.DiceLoss(mode="binary", smooth=1e-5)(o, ts.unsqueeze(1).to(cuda)); l.backward()
+    torch.cuda.synchronize()
+    route2 = m.routing()
+    # (the bs16 record holds forward, backward, backward, forward: compare with its first forward and its first backward)
+    nf = len([r for r in route2 if r[0] == "fwd"])
+    first_fwd16 = [r for r in route16 if r[0] == "fwd"][:nf]
+    assert [r for r in route2 if r[0] == "fwd"] == first_fwd16
+    nb = len([r for r in route2 if r[0] != "fwd"])
+    assert [r for r in route2 if r[0] != "fwd"] == [r for r in route16 if r[0] != "fwd"][:nb]
+    o_ref = ref(xs); l_ref = O.DiceLoss(smooth=1e-5)(o_ref, ts.unsqueeze(1)); l_ref.backward()
+    lg, lr = o.detach().cpu(), o_ref.detach()
+    assert float((lg - lr).abs().max()) < 1e-3
+    assert abs(float(l.detach()) - float(l_ref.detach())) < 1e-5
+    a_, b_ = lg > 0, lr > 0
+    assert float((a_ & b_).sum()) / max(1.0, float((a_ | b_).sum())) > 0.9995
+    gref = dict(ref.named_parameters())
+    for name, p_ in m.named_parameters():
+        g1, g2 = p_.grad.detach().cpu().double().flatten(), gref[name].grad.double().flatten()
+        if float(g2.norm()) > 0:
+            assert float(g1 @ g2 / (g1.norm() * g2.norm())) > 0.9995, name
+    m.set_precision("f32", min_workgroups=0, routing_batch=0)
 
 
 def test_predictor_hipgraph_matches_eager_and_bs1(cuda):
@@ -889,8 +955,15 @@ def test_cli_train_efficientnet_b4_checkpoint_and_predictor(cuda, tmp_path):
     assert torch.isfinite(a).all() and (a - b).abs().max() < 1e-5      # (the SE pooling sums with float atomics: not bitwise)
 
 
-@pytest.mark.parametrize("enc,arch", [("efficientnet-b4", "Unet"), ("resnet50", "UnetPlusPlus")])
-def test_staged_backward_equals_whole_backward(cuda, enc, arch):
+# precision modes the driver-run suite exercises: exact fp32, the bench's f16x3_all under its DEFAULT fill rule
+# (kernel choice follows the launch size), and f16x3_all with the fill threshold at 1 (every eligible layer on the fp16x3 kernels)
+PREC_MODES = [("f32", 0), ("f16x3_all", 0), ("f16x3_all", 1)]
+PREC_IDS = ["f32", "f16x3_all-defaultfill", "f16x3_all-fill1"]
+
+
+@pytest.mark.parametrize("mode,fill", PREC_MODES, ids=PREC_IDS)
+@pytest.mark.parametrize("enc,arch", [("efficientnet-b4", "Unet"), ("resnet50", "UnetPlusPlus"), ("resnet34", "Unet")])
+def test_staged_backward_equals_whole_backward(cuda, enc, arch, mode, fill):
     """The data-parallel step calls uwm_backward one stage (= one gradient bucket) at a time; the gradients must be the
     ones of a single whole-range call (EfficientNet: MBConv block ranges per stage; scratch zeroed in stage 0 only).
     Two runs of the same step differ by atomics-order noise (EfficientNet's `_bn2.bias` gradients ARE such noise, see
@@ -899,6 +972,7 @@ def test_staged_backward_equals_whole_backward(cuda, enc, arch):
     from oracle import unet_oracle as O
     torch.manual_seed(4)
     m = getattr(U, arch)(enc).to(cuda)
+    m.set_precision(mode, min_workgroups=fill)
     m.train()
     m.drop_connect = False
     x, _ = O.synthetic_batch(4, 128, 128, seed=8)
@@ -932,8 +1006,9 @@ def test_staged_backward_equals_whole_backward(cuda, enc, arch):
     assert checked > 50
 
 
+@pytest.mark.parametrize("mode,fill", PREC_MODES, ids=PREC_IDS)
 @pytest.mark.parametrize("arch", ["Unet", "UnetPlusPlus"])
-def test_backward_is_bit_reproducible(cuda, arch):
+def test_backward_is_bit_reproducible(cuda, arch, mode, fill):
     """No float atomics are left on the gradient paths of the ResNet models: the Winograd-domain, 16-channel, head, sub-pixel
     up2, stem and (round 3) flattened implicit-GEMM weight gradients (stride-2 3x3, 1x1 downsample) all sum per-split /
     per-workgroup partials in a fixed order, the head-bias column sum is two-stage.  Two backward passes over the same forward
@@ -943,6 +1018,7 @@ def test_backward_is_bit_reproducible(cuda, arch):
     from oracle import unet_oracle as O
     torch.manual_seed(11)
     m = getattr(U, arch)("resnet34").to(cuda)
+    m.set_precision(mode, min_workgroups=fill, routing_batch=16)      # kernel variants of the benched bs16 step on a one-image batch
     m.train()
     x, _ = O.synthetic_batch(1, 512, 512, seed=3)       # 512^2: every stride-1 3x3 layer is large enough for its Winograd tile
     x = x.to(cuda)
@@ -1054,6 +1130,34 @@ def test_trainer_hipgraph_step_matches_eager(cuda):
         for (n1, r1), (_, r2) in zip(a.state_dict().items(), b.state_dict().items()):
             if n1.endswith("running_var") or n1.endswith("num_batches_tracked"):
                 assert torch.allclose(r1.float(), r2.float(), rtol=5e-3, atol=1e-4), n1
+    # two batch shapes alternating (a partial last batch) and an eval forward of a LARGER batch between replays (validation):
+    # each captured step owns the buffers its kernels address (dlogits / loss scratch of its shape, the workspace block of its
+    # capture), so the replays of one shape are not disturbed by what the other shape or the eval forward allocate
+    torch.manual_seed(5)
+    a = U.Unet("resnet18").to(cuda); b = U.Unet("resnet18").to(cuda)
+    b.load_state_dict(a.state_dict())
+    ta = Trainer(a, w_dice=0.5, w_bce=0.5, lr=1e-3, adam_eps=1e-2)
+    tb = Trainer(b, w_dice=0.5, w_bce=0.5, lr=1e-3, adam_eps=1e-2, use_graph=True)
+    xe, _ = O.synthetic_batch(8, 128, 128, seed=77)
+    for k in range(8):
+        shape = (4, 64, 96) if k % 2 == 0 else (2, 64, 64)
+        x, t = O.synthetic_batch(*shape, seed=40 + k)
+        la = ta.step(x.to(cuda), t.to(cuda)).clone()
+        lb = tb.step(x.to(cuda), t.to(cuda)).clone()
+        assert torch.allclose(la, lb, rtol=0, atol=5e-4), (k, la, lb)
+        if k in (3, 4):                                    # a bigger eval forward re-plans (and re-allocates) the model's workspace
+            for mdl in (a, b):
+                mdl.eval()
+                with torch.no_grad():
+                    junk = mdl(xe.to(cuda))
+                junk.fill_(float("nan"))                   # whatever took over freed blocks is garbage for a graph that still pointed there
+                del junk
+                mdl.train()
+            scratch = [torch.full((1 << 22,), float("nan"), device=cuda) for _ in range(8)]
+            del scratch
+    assert len(tb._graphs) == 2 and tb.opt._step == ta.opt._step == 8
+    assert torch.isfinite(b.flat_parameters()).all()
+    assert float((a.flat_parameters() - b.flat_parameters()).abs().max()) < 2e-3
     # EfficientNet: the drop-connect draw is part of the captured step (device RNG), the step must train
     torch.manual_seed(4)
     m = U.Unet("efficientnet-b4").to(cuda)

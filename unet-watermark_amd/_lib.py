@@ -86,6 +86,9 @@ SIGNATURES = {
     "uwm_set_precision": (I, [P, I]),
     "uwm_get_precision": (I, [P]),
     "uwm_set_precision_fill": (I, [P, I]),
+    "uwm_set_routing_batch": (I, [P, I]),
+    "uwm_routing_enable": (I, [P, I]),
+    "uwm_routing_dump": (L, [P, C.c_char_p, L, I]),
     "uwm_allreduce_grads": (I, [P, P, I, I, P]),
     "uwm_grad_arena": (P, [P]),
     "uwm_set_join_stream": (I, [P, P]),
@@ -129,12 +132,19 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     objdir = _PKG_DIR / "build"
     objdir.mkdir(exist_ok=True)
     procs = []
+    hdr_m = max(p.stat().st_mtime for p in hdrs + [Path(__file__)])
     for s in srcs:
         o = objdir / (s.stem + ".o")
+        if not force and o.exists() and o.stat().st_mtime >= max(s.stat().st_mtime, hdr_m):
+            procs.append((None, None, o))
+            continue
         cmd = [hipcc, f"--offload-arch={HIP_ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(s.name, []) + ["-c", str(s), "-o", str(o)]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), o))
     objs = []
     for cmd, p, o in procs:
+        if p is None:
+            objs.append(str(o))
+            continue
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{out.decode(errors='replace')}")

@@ -786,7 +786,7 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   // the 4-wave kernel (two workgroups per CU hide each other's prologue and epilogue) for the many-tile, short-K ones
   // (layer1 89 vs 93 us, layer2 73 vs 77)
   static const bool force4 = dbg_flag("UWM_F16X3_4WAVE"), force8 = dbg_flag("UWM_F16X3_8WAVE");
-  const long wgs = (long)a.N * tilesH * tilesW * tilesN;
+  const long wgs = (long)route_N(a) * tilesH * tilesW * tilesN;      // (variant choice: ConvArgs::route_n)
   if (a.Ctot == 16) {                                     // one chunk, 16 outputs: the single-chunk form
     const size_t lds1 = (size_t)kFBuf * sizeof(_Float16);          // one patch buffer (25 920 B) >= the epilogue's 4 x 64 x 20 floats
     static DevOnce lds_attr1;

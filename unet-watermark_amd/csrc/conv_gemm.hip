@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
 // long enough for the pipeline to pay anyway (2048 -> 512 at 16^2: 87 vs 106 us; 960 -> 160 at 64^2: 76 vs 72)
 bool conv_gemm_preferred(const ConvArgs& a) {
   if (!conv_gemm_applicable(a) || a.Cout < 48) return false;
-  const long tiles64 = (long)((a.M + kGM - 1) / kGM) * ((a.Cout + 63) / 64);
+  const long tiles64 = (long)((route_M(a) + kGM - 1) / kGM) * ((a.Cout + 63) / 64);
   const long cus = device_cu_count();
   return tiles64 >= 2 * cus || (a.Ctot >= 1024 && tiles64 >= cus);
 }
@@ -275,7 +275,7 @@ hipError_t launch_conv_gemm(const ConvArgs& a, hipStream_t st, int bn) {
     // and for launches with few tiles; 128-channel tiles read X half as often: the long-K layers with plenty of tiles
     // (profiles/r02_*_time_1x1_r50.txt: cfg 864 vs 928 per shape)
     const int pad128 = ((a.Cout + 127) / 128) * 128, pad64 = ((a.Cout + 63) / 64) * 64;
-    const long tilesM = (a.M + kGM - 1) / kGM;
+    const long tilesM = (route_M(a) + kGM - 1) / kGM;
     bn = 128;
     if (a.Cout <= 64 || pad128 * 100 > pad64 * 115 || a.Ctot <= 128 || tilesM * (pad128 / 128) < 4L * device_cu_count()) bn = 64;
   }

@@ -379,7 +379,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (cfg < 0 && conv_patch16_applicable(a)) return launch_conv_patch16(a, st);
   if (cfg < 0 && conv_patch_applicable(a)) {
     // patch-tiled 3x3: pick the channel tile so the launch has >= 512 workgroups when it can
-    const long sp = (long)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    const long sp = (long)route_N(a) * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     int bn = a.Cout >= 128 ? 128 : (a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16));
     if (bn == 128 && sp * ((a.Cout + 127) / 128) < 512) bn = 64;
     return launch_conv_patch(a, st, bn);
@@ -388,13 +388,13 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   {
     // the four classes carry 1 / 2 / 2 / 4 of a 3x3's taps, so the launch is as long as its four-tap class: when that class alone
     // has fewer 128-wide tiles than CUs (layer3 / layer4 at batch 16: 128 / 64 workgroups, 169 / 233 us), 64 x 64 tiles
-    const long t128 = (long)((a.N * (a.Ho >> 1) * (a.Wo >> 1) + 127) / 128) * ((a.Cout + 127) / 128);
+    const long t128 = (long)((route_N(a) * (a.Ho >> 1) * (a.Wo >> 1) + 127) / 128) * ((a.Cout + 127) / 128);
     if (a.Cout > 64 && t128 < device_cu_count()) return launch_s2_dgrad<64, 64, 2, 2>(a, st, 4);
     return a.Cout <= 64 ? launch_s2_dgrad<128, 64, 2, 2>(a, st, 1) : launch_s2_dgrad<128, 128, 2, 2>(a, st, 0);
   }
   if (cfg < 0 && conv_gemm_preferred(a)) return launch_conv_gemm(a, st, 0);      // 1x1 / stride 1, Cin % 32 == 0: persistent LDS-DMA GEMM
   if (cfg < 0) {
-    const long tiles128 = (long)((a.M + 127) / 128);
+    const long tiles128 = (long)((route_M(a) + 127) / 128);
     if (a.Cout <= 16) cfg = 3;
     else if (a.Cout <= 32) cfg = 2;
     else if (a.Cout <= 64) cfg = (tiles128 >= 512) ? 1 : 4;

@@ -460,7 +460,7 @@ hipError_t launch_conv_wino(const ConvArgs& a, hipStream_t st, int bn) {
   if (bn <= 0) {
     bn = a.Cout > 32 ? 64 : (a.Cout > 16 ? 32 : 16);
     // deep, spatially small layers: 64-channel tiles leave half the workgroup slots empty -> 32-channel tiles
-    const long sp = (long)a.N * ((a.Ho + kTH - 1) / kTH) * ((a.Wo + kTW - 1) / kTW);
+    const long sp = (long)route_N(a) * ((a.Ho + kTH - 1) / kTH) * ((a.Wo + kTW - 1) / kTW);
     if (bn == 64 && sp * ((a.Cout + 63) / 64) < 512) bn = 32;
   }
   switch (bn) {

@@ -280,7 +280,7 @@ bool conv_wino8_applicable(const ConvArgs& a) {
   // overlapped train step is 2 % slower (580 vs 590 img/s).  So: forward convolutions only (nothing runs beside them),
   // dgrads stay on the 4-wave kernel; Winograd mode 2 / force_cfg 308 select it wherever the shape allows.
   if (wino_mode_of(a.wino) == 2) return true;
-  const long wgs = (long)a.N * ((a.Ho + kT8 - 1) / kT8) * ((a.Wo + kT8 - 1) / kT8) * ((a.Cout + 63) / 64);
+  const long wgs = (long)route_N(a) * ((a.Ho + kT8 - 1) / kT8) * ((a.Wo + kT8 - 1) / kT8) * ((a.Cout + 63) / 64);
   return a.rmul == 1 && wgs >= 256;      // one 512-thread workgroup per CU: fewer would leave CUs idle
 }
 

@@ -789,6 +789,9 @@ int dbg_int(const char* name, int dflt) {
 }
 
 struct ProfRec { int cls; double flops, bytes; hipEvent_t e0, e1; };
+static thread_local const char* g_route_last = "";
+void route_note(const char* kernel) { g_route_last = kernel; }
+const char* route_last() { return g_route_last; }
 static std::atomic<bool> g_prof{false};
 static std::mutex g_prof_mu;                      // records / event pool: launches may come from one host thread per GPU
 static std::vector<ProfRec> g_recs;

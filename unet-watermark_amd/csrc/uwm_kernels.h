@@ -91,7 +91,12 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int prec;                  // 1: wu is a bf16x3 bank (conv_wino_x3.hip layout) and the launch goes to the split-bf16 kernel; 2: wu is an fp16x3 bank (conv_f16x3.hip: direct form on v_mfma_f32_16x16x32_f16, fp32-class accuracy); 0: fp32
   int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|input| (a dgrad's dY, written by bn_bwd_apply), or nullptr: the input is staged times the power of two that puts that maximum in [2^13, 2^14), undone in the epilogue
+  int route_n;               // > 0: choose the kernel VARIANT as if the batch were route_n images (uwm_set_routing_batch: a small parity sample on the kernels the full batch takes); 0: N
 };
+
+// batch the VARIANT choice of a launcher is made for (ConvArgs::route_n / WgradArgs::route_n; grids always use the real N)
+template <class A> static inline int route_N(const A& a) { return a.route_n > 0 ? a.route_n : a.N; }
+template <class A> static inline long route_M(const A& a) { return a.N > 0 ? (long)a.M / a.N * route_N(a) : (long)a.M; }
 
 // Deferred partial-sum reduces.  A split weight-gradient launch leaves `nsplit` dW-shaped partial images in scratch; adding them
 // up (fixed order) used to be one small launch behind every wgrad (37 per resnet34 step, each 3x slower beside the other
@@ -124,6 +129,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|dy| (written by bn_bwd_apply): dY is staged times the power of two that puts it in [2^13, 2^14)
   ReduceQueue* rq;           // HOST pointer (never read on the device) or nullptr: queue the partial-sum reduce instead of launching it
   int cu_share;              // prec 2: 0 = one workgroup per CU; n = per n/4 of the CUs (3 when the launch runs beside the dependent chain: the rest stay free of its 768-thread workgroups)
+  int route_n;               // as ConvArgs::route_n
 };
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
@@ -133,11 +139,16 @@ enum { kProfClasses = 45 };   // 44 = conv_stem_f16x3 ; 43 = wgrad_f16x3 ; 42 = 
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
+// routing record: every UWM_LAUNCH leaves the name of the kernel it dispatched in a thread-local slot; the model copies it into its
+// per-handle routing log (uwm_routing_dump) so a test / bench.py can assert WHICH kernel a layer ran on
+void route_note(const char* kernel);
+const char* route_last();
 // One profiled launch = one (start, stop) event pair attached to the KERNEL DISPATCH itself (hipExtLaunchKernelGGL): the
 // pair carries the dispatch's own begin / end timestamps — the clock rocprofv3's kernel trace reads — so a launch that
 // waits for CUs behind the other stream's kernels is not charged for the wait (events recorded AROUND the launch were).
 #define UWM_LAUNCH(cls, flops, bytes, kernel, grid, block, lds, st, ...)                                     \
   do {                                                                                                       \
+    route_note(#kernel);                                                                                     \
     if (prof_on()) {                                                                                         \
       hipEvent_t e0_, e1_; prof_pair((cls), (flops), (bytes), &e0_, &e1_);                                   \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0_, e1_, 0, __VA_ARGS__);                         \

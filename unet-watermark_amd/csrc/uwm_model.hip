@@ -139,6 +139,10 @@ struct uwm_model {
   bool hwq_warned = false;
   ReduceQueue rq;                    // partial-sum reduces of the split weight gradients, flushed once per backward stage (uwm_kernels.h)
   int f3_min_wgs = 0;                // fp16x3 kernels: smallest launch (workgroups) they take; 0 = one per CU (uwm_set_precision_fill)
+  int route_n = 0;                   // uwm_set_routing_batch: every size-dependent kernel choice is made as if the batch were this many images (0: the real batch)
+  bool route_log_on = false;         // uwm_routing_enable: record (pass, layer, kernel) of every conv / dgrad / wgrad launch
+  std::string route_log;             // text of the record since the last uwm_routing_dump(.., clear)
+  bool prec_from_env = false;        // the precision mode came from UWM_PRECISION (logged once at the first forward)
   std::vector<char> out_sums;        // per residual block: the BatchNorm-backward sums of its last BatchNorm were made by the dgrad that wrote its output gradient (run_dgrad bn_y)
 };
 
@@ -499,7 +503,7 @@ static void make_plan(uwm_model* m, int N, int H, int W, int training) {
 static bool f3_fwd_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec < UWM_PREC_F16X3 || !cv.f3() || !p.wino_ok(ci)) return false;
-  const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
+  const long wgs = (long)(m->route_n > 0 ? m->route_n : p.N) * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.Cout + 63) / 64);
   return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
 }
 // a decoder conv1's dgrad splits the concat gradient in its epilogue (ConvArgs::out_up): the fp16x3 kernel takes it when the
@@ -509,7 +513,7 @@ static bool stem_f3_on(const uwm_model* m) {
   if (m->stem < 0) return false;
   const ConvL& cv = m->convs[m->stem]; const Plan& p = m->plan;
   if (p.prec < UWM_PREC_F16X3 || !cv.stem7() || !cv.wu_off || p.wino_mode == 0 || dbg_flag("UWM_NO_STEM_F16X3")) return false;
-  const long wgs = (long)p.N * ((p.oh[m->stem] + 15) / 16) * ((p.ow[m->stem] + 15) / 16);
+  const long wgs = (long)(m->route_n > 0 ? m->route_n : p.N) * ((p.oh[m->stem] + 15) / 16) * ((p.ow[m->stem] + 15) / 16);
   return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
 }
 static bool f3d_plain(const uwm_model* m, int ci) {
@@ -526,8 +530,13 @@ static bool f3_wgrad_on(const uwm_model* m, size_t ci) {
 static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
   if (p.prec != UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
-  const long wgs = (long)p.N * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
+  const long wgs = (long)(m->route_n > 0 ? m->route_n : p.N) * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
   return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
+}
+// everything the choice of a dgrad filter bank's FORM depends on (Winograd mode, precision mode, fp16x3 fill rule, routing batch):
+// a change between a forward and its backward re-packs the banks at the start of the backward
+static int pack_key(const uwm_model* m) {
+  return ((m->plan.wino_mode * 8 + m->plan.prec) * 4099 + (m->f3_min_wgs & 0xfff)) * 257 + (m->route_n & 0xff);
 }
 // ------------------------------------------------------------------------------ launch helpers
 struct Ctx {
@@ -544,6 +553,12 @@ static Src lazy_src(const Ctx& c, int conv, int H, int W, int relu = 1, int up =
   const ConvL& cv = c.m->convs[conv];
   const BNL& b = c.m->bns[cv.bn];
   return mk_src(c.F(c.m->plan.y[conv]), cv.CoutP, H, W, c.F(b.f_off) + 2 * b.C, c.F(b.f_off) + 3 * b.C, relu, up);
+}
+
+// routing record (uwm_routing_enable / uwm_routing_dump): "<pass> <layer> <kernel>" per conv-class launch, in launch order
+static hipError_t route_rec(const Ctx& c, const char* pass, int ci, hipError_t e) {
+  if (c.m->route_log_on && e == hipSuccess) { c.m->route_log += pass; c.m->route_log += ' '; c.m->route_log += c.m->convs[ci].name; c.m->route_log += ' '; c.m->route_log += route_last(); c.m->route_log += '\n'; }
+  return e;
 }
 
 static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s1, int Ho, int Wo, float* out,
@@ -567,7 +582,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
                    (double)a.M * cv.CoutP);
   if (ci == c.m->stem && cfg < 0 && stem_f3_on(c.m)) {
     a.wu = c.F(cv.wu_off);
-    if (conv_stem_f16x3_applicable(a)) return launch_conv_stem_f16x3(a, c.st);
+    if (conv_stem_f16x3_applicable(a)) return route_rec(c, "fwd", ci, launch_conv_stem_f16x3(a, c.st));
     a.wu = nullptr;
   }
   if (cv.wu_off && !cv.stem7() && a.Ctot == cv.CinP && c.m->plan.wino_ok((size_t)ci)) {
@@ -578,8 +593,8 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
     }
     if (f3_fwd_on(c.m, (size_t)ci)) { a.prec = 2; a.wu_ncb = f16x3_nj(cv.Cout); a.wu_rinv_off = (int)f16x3_rinv_off(cv.Cout, cv.CinP); }
   }
-  a.wino = c.m->plan.wino_mode + 1;
-  return launch_conv(a, c.st, cfg);
+  a.wino = c.m->plan.wino_mode + 1; a.route_n = c.m->route_n;
+  return route_rec(c, "fwd", ci, launch_conv(a, c.st, cfg));
 }
 
 struct UpSplit { float* gprev; int C0; const float* pmask; const float* pscale; const float* pshift; int accumulate = 0; };
@@ -627,7 +642,8 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
     }
   }
   if (!fused || !*fused) a.bnb_y = nullptr;
-  return launch_conv(a, c.st);
+  a.route_n = c.m->route_n;
+  return route_rec(c, "dgrad", ci, launch_conv(a, c.st));
 }
 
 static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, const float* dy, int Ho, int Wo) {
@@ -642,7 +658,7 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.flops = 2.0 * (double)a.M * cv.Cout * cv.Cin * cv.k * cv.k;
   a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
                    (double)cv.Cout * cv.Kpad);
-  a.wino = c.m->plan.wino_mode + 1;
+  a.wino = c.m->plan.wino_mode + 1; a.route_n = c.m->route_n;
   if (f3_wgrad_on(c.m, (size_t)ci)) { a.prec = 2; a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off()); a.cu_share = (c.wst && c.wst != c.st) ? 3 : 0; }
   // partial images of a split launch: the next free slice of the scratch; their reduce is queued and runs with the other layers'
   // in one launch (flush_reduces: when the scratch / queue fills up and at the end of every backward stage)
@@ -663,9 +679,9 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
     if (e != hipSuccess) return e;
     e = hipStreamWaitEvent(c.wst, covered ? c.m->ev_disp : c.m->ev_fork, 0);
     if (e != hipSuccess) return e;
-    return launch_wgrad(a, c.wst);
+    return route_rec(c, "wgrad", ci, launch_wgrad(a, c.wst));
   }
-  return launch_wgrad(a, c.st);
+  return route_rec(c, "wgrad", ci, launch_wgrad(a, c.st));
 }
 
 static hipError_t run_bn_finalize(const Ctx& c, int bi, size_t count, int training) {
@@ -756,6 +772,11 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
                       hipStream_t st) {
   const Plan& p = m->plan;
   Ctx c{m, ws, st, N};
+  if (m->prec_from_env) {               // say once which arithmetic a process default switched on (a stray variable must not go unnoticed)
+    static const char* names[5] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all"};
+    fprintf(stderr, "libuwm: precision mode %s for this handle comes from UWM_PRECISION (uwm_set_precision overrides it)\n", names[m->prec]);
+    m->prec_from_env = false;
+  }
   // a previous training forward that was never followed by a backward left its dgrad repacks on the side stream with
   // nothing joined to them: this stream must not touch the workspace (re-planned, re-used or re-allocated) before they land
   if (m->packed_in_fwd) HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
@@ -775,7 +796,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
     }
     LCHK(wino_jobs(c, true, m->side));
     HIPCHK(hipEventRecord(m->ev_pack, m->side));
-    m->packed_in_fwd = true; m->pack_mode = p.wino_mode * 8 + p.prec;
+    m->packed_in_fwd = true; m->pack_mode = pack_key(m);
   }
   LCHK(wino_jobs(c, false, st));
   if (stem_f3_on(m)) { const ConvL& sv = m->convs[m->stem]; LCHK(launch_stem_f16x3_weights(m->params + sv.w_off, sv.Kpad, sv.CinP, c.F(sv.wu_off), st)); }
@@ -953,7 +974,7 @@ static int do_backward(uwm_model* m, const float* dlogits, float* ws, int sb, in
     // one memset for every BatchNorm's double scratch (the forward's sum/sumsq halves are dead after bn_finalize)
     HIPCHK(hipMemsetAsync(c.D(p.stat_d), 0, p.stat_d_count * sizeof(double), st));
     if (p.se_gs_floats) HIPCHK(hipMemsetAsync(c.F(p.se_gs_all), 0, p.se_gs_floats * sizeof(float), st));
-    if (m->packed_in_fwd && m->pack_mode == p.wino_mode * 8 + p.prec) {      // (a mode switch between forward and backward: redo them)
+    if (m->packed_in_fwd && m->pack_mode == pack_key(m)) {      // (a mode switch between forward and backward: redo them)
       HIPCHK(hipStreamWaitEvent(st, m->ev_pack, 0));
       m->packed_in_fwd = false;           // joined
     } else {
@@ -1228,8 +1249,10 @@ int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
   m->use_side = e ? atoi(e) : 1;
   if (const char* pe = getenv("UWM_PRECISION")) {      // process default of the precision mode (like UWM_WINOGRAD): f32 | bf16x3 | bf16x3_all | f16x3 | f16x3_all or 0..4
     static const char* names[5] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all"};
-    for (int i = 0; i < 5; ++i) if (!strcmp(pe, names[i]) || (pe[0] == '0' + i && !pe[1])) m->prec = i;
-    m->plan.prec = m->prec;
+    int found = -1;
+    for (int i = 0; i < 5; ++i) if (!strcmp(pe, names[i]) || (pe[0] == '0' + i && !pe[1])) found = i;
+    if (found < 0) { delete m; return fail("uwm_create: UWM_PRECISION=%s is not a precision mode (f32 | bf16x3 | bf16x3_all | f16x3 | f16x3_all or 0..4)", pe); }
+    m->prec = found; m->plan.prec = found; m->prec_from_env = found != UWM_PREC_F32;
   }
   if (const char* pf = getenv("UWM_F16X3_MIN_WGS")) m->f3_min_wgs = atoi(pf) > 0 ? atoi(pf) : 0;      // process default of uwm_set_precision_fill
   m->wino_mode = winograd_mode();       // process default (UWM_WINOGRAD / uwm_set_winograd) at creation; then per handle
@@ -1621,6 +1644,25 @@ int uwm_get_precision(uwm_handle h) { return h ? h->prec : -1; }
 int uwm_set_precision_fill(uwm_handle h, int min_workgroups) {
   if (!h || min_workgroups < 0) return fail("uwm_set_precision_fill: bad argument");
   h->f3_min_wgs = min_workgroups; return 0;
+}
+int uwm_set_routing_batch(uwm_handle h, int batch) {
+  if (!h || batch < 0 || batch > 255) return fail("uwm_set_routing_batch: batch must be 0 (= the real batch) .. 255");
+  h->route_n = batch; return 0;
+}
+int uwm_routing_enable(uwm_handle h, int on) {
+  if (!h) return fail("uwm_routing_enable: null handle");
+  h->route_log_on = on != 0; if (!on) h->route_log.clear();
+  return 0;
+}
+long long uwm_routing_dump(uwm_handle h, char* buf, long long cap, int clear) {
+  if (!h) return -1;
+  const long long need = (long long)h->route_log.size() + 1;
+  if (buf && cap > 0) {
+    const long long n = need <= cap ? need - 1 : cap - 1;
+    memcpy(buf, h->route_log.data(), (size_t)n); buf[n] = 0;
+  }
+  if (clear) h->route_log.clear();
+  return need;
 }
 
 // ---- data-parallel exchange on the C ABI: SUM all-reduce of the gradient arena ranges of backward

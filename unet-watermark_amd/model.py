@@ -228,7 +228,7 @@ class Unet(nn.Module):
     def num_parameters(self) -> int:
         return int(L.lib().uwm_param_count(self._h))
 
-    def set_precision(self, mode: str = "f32", min_workgroups: Optional[int] = None):
+    def set_precision(self, mode: str = "f32", min_workgroups: Optional[int] = None, routing_batch: Optional[int] = None):
         """Arithmetic of the convolution products, per model (uwm_set_precision): "f32" (default: exact fp32 matrix
         instructions); "bf16x3" (opt-in: the backward data-gradient convolutions take each product as a_hi*b_hi + a_hi*b_lo +
         a_lo*b_hi over bf16 halves of the fp32 operands, fp32 accumulation — the forward, hence every logit, is unchanged);
@@ -243,8 +243,22 @@ class Unet(nn.Module):
         L.check(L.lib().uwm_set_precision(self._h, L.PREC[mode]), ValueError)
         if min_workgroups is not None:       # fp16x3 modes: smallest launch the fp16x3 kernels take (default: one workgroup per two CUs)
             L.check(L.lib().uwm_set_precision_fill(self._h, int(min_workgroups)), ValueError)
+        if routing_batch is not None:        # choose kernels as if the batch were this many images (0: the real batch) — uwm_set_routing_batch
+            L.check(L.lib().uwm_set_routing_batch(self._h, int(routing_batch)), ValueError)
         self.precision = mode
         return self
+
+    def routing(self, enable: Optional[bool] = None, clear: bool = True):
+        """Routing record of the library (uwm_routing_enable / uwm_routing_dump): with `enable` switch the record on / off; otherwise
+        return the list of (pass, layer, kernel) of every convolution-class launch since the last call — which HIP kernel each
+        layer's forward / dgrad / wgrad ran on (tests and bench.py assert it for the benched precision mode)."""
+        if enable is not None:
+            L.check(L.lib().uwm_routing_enable(self._h, int(bool(enable))))
+            return self
+        need = int(L.lib().uwm_routing_dump(self._h, None, 0, 0))
+        buf = C.create_string_buffer(max(1, need))
+        L.lib().uwm_routing_dump(self._h, buf, need, int(clear))
+        return [tuple(line.split(" ", 2)) for line in buf.value.decode().splitlines() if line]
 
     def conv_flops(self, h: int, w: int):
         """Algorithmic conv FLOPs per image at h x w: (forward, forward+backward) — SURVEY.md 8(d)."""

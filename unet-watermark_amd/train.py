@@ -340,15 +340,21 @@ class Trainer:
         self._dl = None
         self._scratch = None
         self._loss = None
+        self._shape_bufs = {}
         if self.world > 1:
             broadcast_model(model, 0, group)
 
     def _buffers(self, n, h, w, dev):
+        # one (dlogits, loss scratch, loss) set PER batch shape, kept for the trainer's lifetime: a captured step (use_graph) has their
+        # addresses baked in, so a second shape — a partial last batch — must not hand the first shape's blocks back to the allocator
         cp = self.model._cp
-        if self._dl is None or self._dl.shape != (n, h, w, cp) or self._dl.device != dev:
-            self._dl = torch.empty((n, h, w, cp), dtype=torch.float32, device=dev)
-            self._scratch = torch.empty(8, dtype=torch.float64, device=dev)
-            self._loss = torch.empty(3, dtype=torch.float32, device=dev)
+        key = (n, h, w, cp, dev)
+        ent = self._shape_bufs.get(key)
+        if ent is None:
+            ent = (torch.empty((n, h, w, cp), dtype=torch.float32, device=dev), torch.empty(8, dtype=torch.float64, device=dev),
+                   torch.empty(3, dtype=torch.float32, device=dev))
+            self._shape_bufs[key] = ent
+        self._dl, self._scratch, self._loss = ent
 
     def step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
         """images (N,C,H,W) fp32, masks (N,H,W)|(N,1,H,W) int64|uint8|float32 on the HIP device.
@@ -370,9 +376,13 @@ class Trainer:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss = self._step_eager(gx, gt, graph_opt=True)
-            self._graphs[key] = (g, gx, gt, loss)
+            # every buffer whose address the capture baked in is OWNED by the graph entry: the static input / target copies, the loss
+            # buffers of this shape (self._shape_bufs keeps them too) and the model's workspace block as it was at capture time — a
+            # later forward that needs more bytes (another shape, an eval batch) makes the model allocate a NEW block, and this
+            # reference keeps the captured one alive instead of letting the caching allocator hand it to another tensor
+            self._graphs[key] = (g, gx, gt, loss, (self._dl, self._scratch, self.model._ws))
             return out
-        g, gx, gt, loss = ent
+        g, gx, gt, loss, _owned = ent
         self.opt.sync_hyper(1.0 / self.world)           # (a host compare; writes only after an LR change / restore)
         gx.copy_(images); gt.copy_(masks)
         g.replay()
