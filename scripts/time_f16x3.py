@@ -20,16 +20,27 @@ def timeit(f, reps=20):
     return e0.elapsed_time(e1) * 1e3 / reps      # us
 
 
+CFGS = [int(v) for v in sys.argv[1:]] or [600]      # 600 auto | 601 / 602 / 603: conv_f16x3.hip variants | 604 / 605: conv_f16x3v2.hip 64- / 32-channel tiles
 for name, cin, cout, h in (("layer1", 64, 64, 128), ("layer2", 128, 128, 64), ("layer3", 256, 256, 32), ("layer4", 512, 512, 16),
-                           ("dec2.c2", 64, 64, 128), ("dec1.c1", 384, 128, 64), ("dec0.c1", 768, 256, 32)):
+                           ("dec2.c2", 64, 64, 128), ("dec1.c1", 384, 128, 64), ("dec0.c1", 768, 256, 32), ("dec3.c1", 128, 32, 256), ("dec3.c2", 32, 32, 256)):
     x = torch.randn(N, h, h, cin, device=dev); y = torch.empty(N, h, h, cout, device=dev)
     w = torch.randn(cout, rup(9 * cin, 32), device=dev) * 0.05
     st = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
     s0 = src(x)
-    res = {}
-    for tag, cfg in (("wino", -1), ("f16x3", int(sys.argv[1]) if len(sys.argv) > 1 else 600)):      # 601 / 602 / 603: force a kernel variant
-        f = lambda: L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(w), cout, rup(9 * cin, 32), 3, 3, 1, 1, N, cout, None, P(y), P(st), cfg, stream()))
-        res[tag] = timeit(f)
     fl = 2.0 * N * h * h * cin * cout * 9
-    print(f"{name:8s} {cin:4d}->{cout:4d} {h:3d}^2: wino {res['wino']:7.1f} us ({fl / res['wino'] / 1e6:6.1f} TF alg) | f16x3 {res['f16x3']:7.1f} us "
-          f"({fl / res['f16x3'] / 1e6:6.1f} TF alg, {3 * fl / res['f16x3'] / 1e6 / 2500:.3f} of the f16 peak)   (both include their filter-bank launch)")
+    ref = None
+    line = f"{name:8s} {cin:4d}->{cout:4d} {h:3d}^2:"
+    for cfg in [-1] + CFGS:
+        f = lambda: L.lib().uwm_op_conv(C.byref(s0), None, P(w), cout, rup(9 * cin, 32), 3, 3, 1, 1, N, cout, None, P(y), P(st), cfg, stream())
+        y.zero_()
+        if f() != 0:
+            line += f" | {cfg}: n/a"
+            continue
+        t = timeit(lambda: L.check(f()))
+        if ref is None:
+            ref = y.clone()
+            line += f" wino {t:6.1f} us ({fl / t / 1e6:5.1f} TF)"
+        else:
+            err = float((y - ref).abs().max() / ref.abs().max())
+            line += f" | {cfg}: {t:6.1f} us ({fl / t / 1e6:5.1f} TF alg, util {3 * fl / t / 1e6 / 2500:.3f}, relerr {err:.1e})"
+    print(line + "   (op entry: filter-bank launches included)", flush=True)

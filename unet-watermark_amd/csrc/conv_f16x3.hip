@@ -55,7 +55,6 @@ size_t f16x3_bank_floats(int rows, int chans) {          // in floats (the model
   const size_t halfs = (size_t)(chans / 16) * kFKs * f16x3_nj(rows) * 2 * 64 * 8;
   return halfs / 2 + (size_t)f16x3_nj(rows) * 16;
 }
-static inline __host__ __device__ size_t f16x3_rinv_off_floats(int rows, int chans) { return (size_t)(chans / 16) * 5 * (size_t)(((rows + 63) / 64) * 4) * 512; }
 size_t f16x3_rinv_off(int rows, int chans) { return f16x3_rinv_off_floats(rows, chans); }
 
 __device__ __forceinline__ float f16x3_wval(const WinoJob& jb, int row, int slot, int ch) {
@@ -118,6 +117,7 @@ __global__ __launch_bounds__(256) void f16x3_rowscale_kernel(const WinoJobs jobs
 }
 __global__ __launch_bounds__(256) void f16x3_weights_multi_kernel(const WinoJobs jobs) {
   const WinoJob jb = jobs.j[blockIdx.y];
+  if (jb.pad_ == 1) return;                            // layout 1: f16x3v2_weights_multi_kernel
   const int nJ = f16x3_nj_(jb.rows);
   const size_t total = (size_t)(jb.chans / 16) * kFKs * nJ * 64;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -155,7 +155,8 @@ hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st) {
   hipLaunchKernelGGL(f16x3_rowmax_kernel, dim3((unsigned)((mr + 3) / 4), (unsigned)jobs.n, 8), dim3(256), 0, st, jobs);
   hipLaunchKernelGGL(f16x3_rowscale_kernel, dim3((unsigned)((mr + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);
   hipLaunchKernelGGL(f16x3_weights_multi_kernel, dim3((unsigned)((mx + 255) / 256), (unsigned)jobs.n), dim3(256), 0, st, jobs);
-  return hipGetLastError();
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) return e; }
+  return launch_f16x3v2_weights_multi(jobs, st);
 }
 
 // Concat-split epilogue of a decoder conv1 dgrad (ConvArgs::out_up; the contract of conv_wino_kernel's): the output channels
@@ -774,6 +775,8 @@ bool conv_f16x3_applicable(const ConvArgs& a) {
 }
 
 hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
+  if (a.wu_layout == 1) return launch_conv_f16x3v2(a, st, variant >= 4 ? variant : 0);      // the bank is a conv_f16x3v2.hip one
+  if (variant >= 4) return hipErrorInvalidValue;
   if (!conv_f16x3_applicable(a)) return hipErrorInvalidValue;
   if (a.out_up && (a.addend || a.mask || a.bias || a.bnb_y || (a.ssum && !a.bnb_mean) || (a.up_c0 < a.Cout && !a.out))) return hipErrorInvalidValue;
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum)) return hipErrorInvalidValue;

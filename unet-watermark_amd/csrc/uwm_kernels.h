@@ -92,6 +92,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|input| (a dgrad's dY, written by bn_bwd_apply), or nullptr: the input is staged times the power of two that puts that maximum in [2^13, 2^14), undone in the epilogue
   int route_n;               // > 0: choose the kernel VARIANT as if the batch were route_n images (uwm_set_routing_batch: a small parity sample on the kernels the full batch takes); 0: N
+  int wu_layout;             // prec 2: layout of the fp16x3 bank behind wu — 0: conv_f16x3.hip (tap pairs, 16-row fragments), 1: conv_f16x3v2.hip (taps, 32-row fragments); set by whoever packed the bank (f16x3v2_shape)
 };
 
 // batch the VARIANT choice of a launcher is made for (ConvArgs::route_n / WgradArgs::route_n; grids always use the real N)
@@ -217,8 +218,15 @@ hipError_t launch_wino_weights_x3_multi(const WinoJobs& jobs, hipStream_t st);
 int f16x3_nj(int rows);
 size_t f16x3_bank_floats(int rows, int chans);             // bank size in floats, 1 / row-scale array included
 size_t f16x3_rinv_off(int rows, int chans);                 // float offset of that array in the bank
-hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st);
+hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st);      // WinoJob::pad_ = bank layout (ConvArgs::wu_layout)
 bool conv_f16x3_applicable(const ConvArgs& a);
+static inline __host__ __device__ size_t f16x3_rinv_off_floats(int rows, int chans) { return (size_t)(chans / 16) * 5 * (size_t)(((rows + 63) / 64) * 4) * 512; }
+// conv_f16x3v2.hip: the same arithmetic on v_mfma_f32_32x32x16_f16, 8 x 32-pixel tiles (bank layout 1)
+bool f16x3v2_shape(int Ho, int Wo, int rows, int chans);      // shapes it takes (whole tiles, 32-row fragments): decides the bank layout
+int f16x3v2_nf(int rows);
+hipError_t launch_f16x3v2_weights_multi(const WinoJobs& jobs, hipStream_t st);      // the layout-1 jobs of a job table (row scales already made)
+bool conv_f16x3v2_applicable(const ConvArgs& a);
+hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant = 0);      // variant: 0 auto | 4 64-channel tiles | 5 32-channel tiles
 // conv_stem_f16x3.hip: the 7x7 / stride-2 ResNet stem on the fp16x3 arithmetic (one MFMA k-step per kernel row); a.wu = its bank
 size_t stem_f16x3_bank_floats();
 hipError_t launch_stem_f16x3_weights(const float* w, int Kpad, int cin_p, float* bank, hipStream_t st);

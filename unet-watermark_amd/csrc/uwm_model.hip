@@ -533,6 +533,18 @@ static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const long wgs = (long)(m->route_n > 0 ? m->route_n : p.N) * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
   return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
 }
+// layout of a layer's fp16x3 bank (ConvArgs::wu_layout): 1 = conv_f16x3v2.hip (32x32x16 MFMA, 8 x 32-pixel tiles) where the map is
+// tiled by whole tiles and the output rows by 32-row fragments (a decoder conv1 dgrad with the fused concat split: 64-row tiles)
+static int f3_layout(const uwm_model* m, size_t ci, bool dgrad) {
+  const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
+  const int rows = dgrad ? cv.CinP : cv.Cout, chans = dgrad ? cv.CoutP : cv.CinP;
+  if (rows != (dgrad ? cv.CinP : cv.CoutP)) return 0;
+  if (dgrad && !f3d_plain(m, (int)ci)) return 0;
+  bool split = false;
+  if (dgrad) { for (auto& d : m->dec) if (d.c1 == (int)ci) split = true; for (auto& nd : m->nodes) if (nd.c1 == (int)ci) split = true; }
+  if (split && (rows & 63)) return 0;
+  return f16x3v2_shape(p.oh[ci], p.ow[ci], rows, chans) ? 1 : 0;
+}
 // everything the choice of a dgrad filter bank's FORM depends on (Winograd mode, precision mode, fp16x3 fill rule, routing batch):
 // a change between a forward and its backward re-packs the banks at the start of the backward
 static int pack_key(const uwm_model* m) {
@@ -591,7 +603,10 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
       if (a.C0 != cv.c0 && a.C0 != a.Ctot) return hipErrorInvalidValue;       // the bank was split for this concat boundary
       a.prec = 1;
     }
-    if (f3_fwd_on(c.m, (size_t)ci)) { a.prec = 2; a.wu_ncb = f16x3_nj(cv.Cout); a.wu_rinv_off = (int)f16x3_rinv_off(cv.Cout, cv.CinP); }
+    if (f3_fwd_on(c.m, (size_t)ci)) {
+      a.prec = 2; a.wu_layout = f3_layout(c.m, (size_t)ci, false);
+      a.wu_ncb = a.wu_layout == 1 ? f16x3v2_nf(cv.Cout) : f16x3_nj(cv.Cout); a.wu_rinv_off = (int)f16x3_rinv_off(cv.Cout, cv.CinP);
+    }
   }
   a.wino = c.m->plan.wino_mode + 1; a.route_n = c.m->route_n;
   return route_rec(c, "fwd", ci, launch_conv(a, c.st, cfg));
@@ -623,7 +638,8 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
     const int pm = c.m->plan.prec;
     if ((pm == UWM_PREC_BF16X3 || pm == UWM_PREC_BF16X3_ALL) && cv.x3_d()) a.prec = 1;
     if (f3_dgrad_on(c.m, (size_t)ci) && (!us || (us->C0 & 63) == 0)) {        // fp16x3 direct form: dY scaled by the power of two bn_bwd_apply's max|dy| calls for
-      a.prec = 2; a.wu_ncb = f16x3_nj(cv.CinP); a.wu_rinv_off = (int)f16x3_rinv_off(cv.CinP, cv.CoutP);
+      a.prec = 2; a.wu_layout = f3_layout(c.m, (size_t)ci, true);
+      a.wu_ncb = a.wu_layout == 1 ? f16x3v2_nf(cv.CinP) : f16x3_nj(cv.CinP); a.wu_rinv_off = (int)f16x3_rinv_off(cv.CinP, cv.CoutP);
       a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off());
     }
   }
@@ -756,7 +772,7 @@ static hipError_t wino_jobs(const Ctx& c, bool dgrad, hipStream_t st) {
       else { if (prec == UWM_PREC_BF16X3_ALL && cv.x3()) kind = 1; if (f3_fwd_on(m, ci)) kind = 2; }
       if (kind != x3) continue;
       WinoJob& j = jobs.j[jobs.n++];
-      j.w = m->params + cv.w_off; j.Kpad = cv.Kpad; j.pad_ = 0;
+      j.w = m->params + cv.w_off; j.Kpad = cv.Kpad; j.pad_ = kind == 2 ? f3_layout(m, ci, dgrad) : 0;
       if (dgrad) { j.ut = c.F(cv.wud_off); j.rows = cv.CinP; j.chans = cv.CoutP; j.mode = 2; j.src_rows = cv.Cout; }
       else { j.ut = c.F(cv.wu_off); j.rows = cv.Cout; j.chans = cv.CinP; j.mode = 0; j.src_rows = cv.Cout; }
       if (jobs.n == 40) { hipError_t e = flush(); if (e != hipSuccess) return e; }
@@ -1580,7 +1596,7 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st, bool x3 = fa
   return 0;
 }
 // fp16x3 bank for the op-level entry point (tests / timing): cfg 600
-static int op_f16x3_prepare(ConvArgs& a, hipStream_t st) {
+static int op_f16x3_prepare(ConvArgs& a, hipStream_t st, int variant = 0) {
   static float* buf = nullptr; static size_t cap = 0;
   if ((a.Ctot & 31) && !(a.Ctot == 16 && a.Cout <= 16)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs channels %% 32 == 0 (or the 16 -> 16 single-chunk layer)");
   const size_t need = f16x3_bank_floats(a.wrows, a.Ctot);
@@ -1591,9 +1607,11 @@ static int op_f16x3_prepare(ConvArgs& a, hipStream_t st) {
   }
   WinoJobs jobs; jobs.n = 1;
   WinoJob& j = jobs.j[0];
-  j.w = a.w; j.ut = buf; j.rows = a.wrows; j.chans = a.Ctot; j.Kpad = a.Kpad; j.mode = 0; j.src_rows = a.wrows; j.pad_ = 0;
+  // bank layout: 601-603 force a conv_f16x3.hip kernel (layout 0), 604 / 605 a conv_f16x3v2.hip one (layout 1), 600 = what the model would take
+  const int layout = variant >= 4 ? 1 : (variant == 0 && f16x3v2_shape(a.Ho, a.Wo, a.wrows, a.Ctot) && a.wrows == a.Cout ? 1 : 0);
+  j.w = a.w; j.ut = buf; j.rows = a.wrows; j.chans = a.Ctot; j.Kpad = a.Kpad; j.mode = 0; j.src_rows = a.wrows; j.pad_ = layout;
   LCHK(launch_f16x3_weights_multi(jobs, st));
-  a.wu = buf; a.wu_ncb = f16x3_nj(a.wrows); a.wu_rinv_off = (int)f16x3_rinv_off(a.wrows, a.Ctot); a.prec = 2;
+  a.wu = buf; a.wu_layout = layout; a.wu_ncb = layout == 1 ? f16x3v2_nf(a.wrows) : f16x3_nj(a.wrows); a.wu_rinv_off = (int)f16x3_rinv_off(a.wrows, a.Ctot); a.prec = 2;
   return 0;
 }
 static bool op_wino_shape(const ConvArgs& a, int kh, int kw, int stride, int pad) {
@@ -1721,9 +1739,9 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
     LCHK(launch_conv_stem_f16x3(a, (hipStream_t)stream));
     return 0;
   }
-  if (cfg >= 600 && cfg <= 603) {                     // 600 auto | 601 four-wave kernel | 602 eight-wave kernel | 603 four-wave, 32-channel tiles
+  if (cfg >= 600 && cfg <= 605) {                     // 600 auto | 601 four-wave kernel | 602 eight-wave kernel | 603 four-wave, 32-channel tiles | 604 / 605 conv_f16x3v2 64- / 32-channel tiles
     if (!op_wino_shape(a, kh, kw, stride, pad)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs 3x3 s1 p1, Ho >= 8, Wo >= 16");
-    if (op_f16x3_prepare(a, (hipStream_t)stream)) return 1;
+    if (op_f16x3_prepare(a, (hipStream_t)stream, cfg - 600)) return 1;
   } else if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
     if (op_wino_prepare(a, 0, (hipStream_t)stream, cfg == 400)) return 1;
   } else if (cfg >= 300 && cfg < 500) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
