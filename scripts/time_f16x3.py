@@ -36,11 +36,15 @@ for name, cin, cout, h in (("layer1", 64, 64, 128), ("layer2", 128, 128, 64), ("
         if f() != 0:
             line += f" | {cfg}: n/a"
             continue
-        t = timeit(lambda: L.check(f()))
+        if cfg >= 600:                                  # kernel only: the bank of the call above is reused (cfg + 1000)
+            g = lambda: L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(w), cout, rup(9 * cin, 32), 3, 3, 1, 1, N, cout, None, P(y), P(st), cfg + 1000, stream()))
+            t = timeit(g)
+        else:
+            t = timeit(lambda: L.check(f()))
         if ref is None:
             ref = y.clone()
             line += f" wino {t:6.1f} us ({fl / t / 1e6:5.1f} TF)"
         else:
             err = float((y - ref).abs().max() / ref.abs().max())
             line += f" | {cfg}: {t:6.1f} us ({fl / t / 1e6:5.1f} TF alg, util {3 * fl / t / 1e6 / 2500:.3f}, relerr {err:.1e})"
-    print(line + "   (op entry: filter-bank launches included)", flush=True)
+    print(line + "   (wino: op entry with its filter transform; fp16x3: kernel alone)", flush=True)

@@ -25,6 +25,7 @@
 // Reference semantics replaced: the 3x3 convolutions of smp.Unet's encoder / decoder forward and their input gradients
 // (/root/reference/src/models/unet_model.py:64-71 -> SURVEY.md §8 a5-a8, a10, a14).
 #include "uwm_kernels.h"
+#include <type_traits>
 
 namespace uwm {
 
@@ -37,6 +38,12 @@ typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #ifndef UWM_F16V2_ABL
 #define UWM_F16V2_ABL 0       // compile-time timing ablations: 1 no MFMA, 2 no filter loads, 4 no pixel-fragment LDS reads, 8 no patch loads / stores; 0 in the product build
+#endif
+#ifndef UWM_V2_COSLOW_BYTES
+#define UWM_V2_COSLOW_BYTES (2u << 20)      // filter bytes of all channel tiles beyond which the tile walk keeps one channel tile per XCD
+#endif
+#ifndef UWM_V2_AD
+#define UWM_V2_AD 3           // filter-fragment register sets of the 4-wave kernel (prefetch distance UWM_V2_AD - 1 taps; 3 over 2: layer3 69 -> 57 us, decoder block 0 conv1 171 -> 152)
 #endif
 constexpr int kVH = 8, kVW = 32;                       // output tile
 constexpr int kVPW = kVW + 2, kVPH = kVH + 2, kVPP = kVPW * kVPH;      // 34 x 10 = 340 patch pixels
@@ -120,6 +127,117 @@ __device__ __forceinline__ void split4(f4 x, u2& hi, u2& lo) {
   lo.x = l0; lo.y = l1;
 }
 
+// ---------------------------------------------------------------- epilogue (shared by the 4-wave and the 8-wave kernel)
+// R = one MMA wave's block [64 pixels = 2 image rows x 32][kVQLd floats] (raw accumulators); this wave finishes pixels
+// [p0, p0 + np) of it with lanes along the channels (whole 128- / 256-byte pixel rows per store): row un-scale, bias, residual
+// addend, ReLU mask, BatchNorm statistics / fused BatchNorm-backward sums — conv_f16x3_kernel's contract.  hb = image row of the
+// block's first row.  The concat-split form (ConvArgs::out_up, NCF = 2 only) sums 2 x 2 pixel blocks and needs np = 64.
+template <int NCF>
+__device__ __forceinline__ void v2_epilogue(const ConvArgs& a, const float* R, int p0, int np, int n, int hb, int w0, int n0, int lane,
+                                            float ixs, f4& ps_, f4& pq_) {
+  constexpr int kCo = 32 * NCF, kCQ = kCo / 4, kSub = 64 / kCQ;
+  const float* rinv = (const float*)a.wu + a.wu_rinv_off;
+  const bool bnb = a.bnb_mean != nullptr;
+  const int cq = lane & (kCQ - 1), sub = lane / kCQ;
+  const int co = n0 + cq * 4;
+  const bool cok = co < a.Cout;
+  if (NCF == 2 && a.out_up != nullptr) {
+    f4 rs = {0.f, 0.f, 0.f, 0.f};
+    if (cok) rs = *(const f4*)(rinv + co) * ixs;
+    if (cok) {
+      if (n0 < a.up_c0) {
+        f4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = bmu, msc = {1.f, 1.f, 1.f, 1.f}, msh = bmu;
+        if (bnb) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
+        if (a.up_mscale) { msc = *(const f4*)(a.up_mscale + co); msh = *(const f4*)(a.up_mshift + co); }
+#pragma unroll
+        for (int r = 0; r < 16 / kSub; ++r) {
+          const int bx = r * kSub + sub;                   // block column 0..15
+          const float* q = R + (2 * bx) * kVQLd + cq * 4;
+          f4 v = (*(const f4*)q + *(const f4*)(q + kVQLd) + *(const f4*)(q + 32 * kVQLd) + *(const f4*)(q + 33 * kVQLd)) * rs;
+          const size_t o2 = (((size_t)n * (a.Ho >> 1) + (hb >> 1)) * (a.Wo >> 1) + ((w0 >> 1) + bx)) * a.up_c0 + co;
+          if (a.up_mask) {
+            f4 mk = *(const f4*)(a.up_mask + o2);
+            const f4 yr = mk;
+            if (a.up_mscale) mk = mk * msc + msh;
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            if (bnb) { ps_ += v; pq_ += v * ((yr - bmu) * brs); }
+          }
+          if (a.up_accum) v += *(const f4*)(a.out_up + o2);
+          *(f4*)(a.out_up + o2) = v;
+        }
+      } else {
+        const int c1n = a.Cout - a.up_c0;
+#pragma unroll 4
+        for (int r = 0; r < 64 / kSub; ++r) {
+          const int p = r * kSub + sub;
+          const int ho = hb + (p >> 5), wo = w0 + (p & 31);
+          *(f4*)(a.out + (((size_t)n * a.Ho + ho) * a.Wo + wo) * c1n + (co - a.up_c0)) = *(const f4*)(R + p * kVQLd + cq * 4) * rs;
+        }
+      }
+    }
+    return;
+  }
+  f4 rs = {0.f, 0.f, 0.f, 0.f}, bmu = rs, brs = rs, bia = rs, msc = {1.f, 1.f, 1.f, 1.f}, msh = rs;
+  if (cok) rs = *(const f4*)(rinv + co) * ixs;
+  if (bnb && cok) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
+  if (a.bias && cok) bia = *(const f4*)(a.bias + co);
+  if (a.mscale && cok) { msc = *(const f4*)(a.mscale + co); msh = *(const f4*)(a.mshift + co); }
+#pragma unroll 4
+  for (int r = 0; r < np / kSub; ++r) {
+    const int p = p0 + r * kSub + sub;
+    const int ho = hb + (p >> 5), wo = w0 + (p & 31);
+    if (cok) {
+      const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
+      f4 v = *(const f4*)(R + p * kVQLd + cq * 4) * rs + bia;
+      if (a.addend) v += *(const f4*)(a.addend + o);
+      f4 yr = {0.f, 0.f, 0.f, 0.f};
+      if (a.mask) {
+        f4 mk = *(const f4*)(a.mask + o);
+        yr = mk;
+        if (a.mscale) mk = mk * msc + msh;
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      *(f4*)(a.out + o) = v;
+      if (a.bnb_y) yr = *(const f4*)(a.bnb_y + o);
+      ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
+    }
+  }
+}
+// per-channel (sum, sum of squares | BatchNorm-backward sums) of the workgroup: pixel sub-rows of a wave by shuffles, the NW waves
+// through LDS (red: dead LDS, [NW][64][2] floats), one fp64 atomic pair per channel on one of the replicas
+template <int NCF, int NW>
+__device__ __forceinline__ void v2_stats(const ConvArgs& a, float* red, f4 ps_, f4 pq_, int n0, int tid, int lane, int wave) {
+  constexpr int kCo = 32 * NCF, kCQ = kCo / 4;
+  const int cq = lane & (kCQ - 1), sub = lane / kCQ;
+  const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;       // channels the statistics cover
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float sv = ps_[e], qv = pq_[e];
+#pragma unroll
+    for (int d = kCQ; d < 64; d <<= 1) { sv += __shfl_xor(sv, d); qv += __shfl_xor(qv, d); }
+    ps_[e] = sv; pq_[e] = qv;
+  }
+  __syncthreads();                             // every wave is done with the blocks
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[(wave * 64 + cq * 4 + e) * 2] = ps_[e]; red[(wave * 64 + cq * 4 + e) * 2 + 1] = pq_[e]; }
+  }
+  __syncthreads();
+  if (tid < kCo) {
+    const int c1 = n0 + tid;
+    if (c1 < stat_c) {
+      double sv = 0.0, qv = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { sv += (double)red[(w * 64 + tid) * 2]; qv += (double)red[(w * 64 + tid) * 2 + 1]; }
+      const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
+      atomicAdd(a.ssum + srep_off + c1, sv);
+      atomicAdd(a.ssq + srep_off + c1, qv);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- main kernel
 template <int NCF>
 __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) {
@@ -136,9 +254,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
   unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tilesN = (a.Cout + kCo - 1) / kCo;
   const int tilesW = a.Wo / kVW, tilesH = a.Ho / kVH;
-  const int tn = tile % tilesN; tile /= tilesN;
-  const int tw = tile % tilesW; tile /= tilesW;
-  const int th = tile % tilesH; const int n = tile / tilesH;
+  // tile order inside an XCD's contiguous range: channel tile fastest (the channel tiles of one pixel tile share the patch in L2)
+  // while all their filter slices fit the XCD's 4-MB L2 beside the streams; else channel tile SLOWEST — an XCD then works on one
+  // filter slice (Ctot x 2304 bytes per 64 channels), which stays L2-resident, and streams the patches
+  int tn, tw, th, n;
+  if ((size_t)tilesN * a.Ctot * (36 * kCo) > (size_t)UWM_V2_COSLOW_BYTES) {
+    const int pixt = tilesW * tilesH * a.N;
+    tn = tile / pixt; tile -= tn * pixt;
+    tw = tile % tilesW; tile /= tilesW;
+    th = tile % tilesH; n = tile / tilesH;
+  } else {
+    tn = tile % tilesN; tile /= tilesN;
+    tw = tile % tilesW; tile /= tilesW;
+    th = tile % tilesH; n = tile / tilesH;
+  }
   const int n0 = tn * kCo, h0 = th * kVH, w0 = tw * kVW;
   const int nF = a.wu_ncb;
 
@@ -251,9 +380,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
       for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
   };
 
-  h8 wA_hi[NCF], wA_lo[NCF], wB_hi[NCF], wB_lo[NCF];
-  h8 xA_h[2], xA_l[2], xB_h[2], xB_l[2];
-  w_load(0, wA_hi, wA_lo);
+  // filter-fragment ring: kAD register sets, the loads of tap t + kAD - 1 are issued while tap t is multiplied (9 taps per chunk:
+  // set = tap % kAD with kAD = 3 divides evenly, so one chunk per loop trip)
+  constexpr int kAD = UWM_V2_AD;
+  h8 w_hi[kAD][NCF], w_lo[kAD][NCF];
+  h8 x_h[2][2], x_l[2][2];
+#pragma unroll
+  for (int d = 0; d < kAD - 1; ++d) w_load(d < nsteps ? d : nsteps - 1, w_hi[d], w_lo[d]);
   chunk_src(0);
 #pragma unroll
   for (int rd = 0; rd < kVRounds - 1; ++rd) pv[rd] = *(const f4*)(lsp + goff[rd]);
@@ -272,27 +405,27 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
 
   // Iteration c multiplies chunk c (buffer c & 1) and, between the MFMAs of taps 0-5, converts and stores the six rounds of
   // chunk c+1 (raw values fetched during iteration c-1) into the other buffer, re-issuing each round's global load for chunk c+2.
-  // Two chunks per loop trip (nchunk is even): register sets alternate statically (9 taps per chunk: odd).
-  for (int cc = 0; cc < nchunk; cc += 2) {
+  // kTrip chunks per loop trip so that every register set index is static (taps per trip % kAD == 0, chunks per trip even).
+  constexpr int kTrip = (kAD == 3) ? 2 : 2;              // (9 * 2) % 2 == 0 and (9 * 2) % 3 == 0
+  for (int cc = 0; cc < nchunk; cc += kTrip) {
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int c = cc + hh, cur = hh, nxt = hh ^ 1;
+    for (int hh = 0; hh < kTrip; ++hh) {
+      const int c = cc + hh, cur = hh & 1, nxt = cur ^ 1;
       const bool more1 = c + 1 < nchunk;
       coef_load(more1 ? c + 1 : c);
       chunk_src(c + 2 < nchunk ? c + 2 : nchunk - 1);      // (past the end: a harmless re-fetch)
       const char* pc = vsm + cur * kVBuf;
-      x_load(0, pc, xA_h, xA_l);
+      x_load(0, pc, x_h[0], x_l[0]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 9; ++ks) {
         const int t = c * 9 + ks;
-        const int tnext = t + 1 < nsteps ? t + 1 : t;
-        const bool wsel = ((hh * 9 + ks) & 1) == 0, xsel = (ks & 1) == 0;
-        // next tap's operands first: filter fragments from L1 / L2, pixel fragments from LDS
-        if (wsel) w_load(tnext, wB_hi, wB_lo); else w_load(tnext, wA_hi, wA_lo);
-        if (ks < 8) { if (xsel) x_load(ks + 1, pc, xB_h, xB_l); else x_load(ks + 1, pc, xA_h, xA_l); }
-        if (wsel) { if (xsel) mma(wA_hi, wA_lo, xA_h, xA_l); else mma(wA_hi, wA_lo, xB_h, xB_l); }
-        else { if (xsel) mma(wB_hi, wB_lo, xA_h, xA_l); else mma(wB_hi, wB_lo, xB_h, xB_l); }
+        const int tp = t + kAD - 1 < nsteps ? t + kAD - 1 : nsteps - 1;
+        const int ws = (hh * 9 + ks) % kAD, wl = (hh * 9 + ks + kAD - 1) % kAD, xsn = ks & 1;
+        // operands ahead first: filter fragments from L1 / L2 (kAD - 1 taps ahead), pixel fragments from LDS (next tap)
+        w_load(tp, w_hi[wl], w_lo[wl]);
+        if (ks < 8) x_load(ks + 1, pc, x_h[xsn ^ 1], x_l[xsn ^ 1]);
+        mma(w_hi[ws], w_lo[ws], x_h[xsn], x_l[xsn]);
         if (!(dbg & 8) && ks < kVRounds) {
           if (ks < kVRounds - 1) {
             store_unit(nxt, ks, pv[ks]);                   // (past the last chunk: into the dead buffer)
@@ -330,110 +463,282 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
       for (int q = 0; q < 4; ++q)
         *(f4*)(R + (i * 32 + pcol) * kVQLd + j * 32 + q * 8 + kh * 4) = (f4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
   __syncthreads();
-  const float* rinv = (const float*)a.wu + a.wu_rinv_off;
-  const float ixs = 1.f / xs;
-  const bool do_stats = a.ssum != nullptr;
-  const bool bnb = a.bnb_mean != nullptr;
-  const int cq = lane & (kCQ - 1), sub = lane / kCQ;
-  const int co = n0 + cq * 4;
-  const bool cok = co < a.Cout;
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
-  const int stat_c = a.out_up != nullptr ? a.up_c0 : a.Cout;       // channels the statistics cover
-  const int hb = h0 + 2 * wave;                            // image row of this wave's first pixel row
-  if (NCF == 2 && a.out_up != nullptr) {
-    // concat-split epilogue of a decoder conv1 dgrad (ConvArgs::out_up, conv_wino_kernel's contract): channels [0, up_c0) are summed
-    // over each 2 x 2 pixel block (this wave's two rows x 16 column pairs), ReLU-masked by the low-resolution producer, written at
-    // half resolution with the fused BatchNorm-backward sums; channels [up_c0, Cout) go to `out` at full resolution
-    f4 rs = {0.f, 0.f, 0.f, 0.f};
-    if (cok) rs = *(const f4*)(rinv + co) * ixs;
-    if (cok) {
-      if (n0 < a.up_c0) {
-        f4 bmu = {0.f, 0.f, 0.f, 0.f}, brs = bmu, msc = {1.f, 1.f, 1.f, 1.f}, msh = bmu;
-        if (bnb) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
-        if (a.up_mscale) { msc = *(const f4*)(a.up_mscale + co); msh = *(const f4*)(a.up_mshift + co); }
-#pragma unroll
-        for (int r = 0; r < 16 / kSub; ++r) {
-          const int bx = r * kSub + sub;                   // block column 0..15
-          const float* q = R + (2 * bx) * kVQLd + cq * 4;
-          f4 v = (*(const f4*)q + *(const f4*)(q + kVQLd) + *(const f4*)(q + 32 * kVQLd) + *(const f4*)(q + 33 * kVQLd)) * rs;
-          const size_t o2 = (((size_t)n * (a.Ho >> 1) + (hb >> 1)) * (a.Wo >> 1) + ((w0 >> 1) + bx)) * a.up_c0 + co;
-          if (a.up_mask) {
-            f4 mk = *(const f4*)(a.up_mask + o2);
-            const f4 yr = mk;
-            if (a.up_mscale) mk = mk * msc + msh;
-            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-            if (bnb) { ps_ += v; pq_ += v * ((yr - bmu) * brs); }
-          }
-          if (a.up_accum) v += *(const f4*)(a.out_up + o2);
-          *(f4*)(a.out_up + o2) = v;
-        }
-      } else {
-        const int c1n = a.Cout - a.up_c0;
-#pragma unroll 4
-        for (int r = 0; r < 64 / kSub; ++r) {
-          const int p = r * kSub + sub;
-          const int ho = hb + (p >> 5), wo = w0 + (p & 31);
-          *(f4*)(a.out + (((size_t)n * a.Ho + ho) * a.Wo + wo) * c1n + (co - a.up_c0)) = *(const f4*)(R + p * kVQLd + cq * 4) * rs;
-        }
-      }
-    }
+  v2_epilogue<NCF>(a, R, 0, 64, n, h0 + 2 * wave, w0, n0, lane, 1.f / xs, ps_, pq_);
+  if (a.ssum != nullptr) v2_stats<NCF, 4>(a, (float*)vsm, ps_, pq_, n0, tid, lane, wave);
+}
+
+// ---------------------------------------------------------------- 8-wave kernel: MMA waves and loader waves
+// What holds the 4-wave kernel back (compile-time ablations, profiles/r04_e_ablate_v2.txt: the MFMAs alone 85 us on 768 -> 256 at
+// 32^2, + pixel-fragment LDS reads 93, + filter loads 103, + patch staging alone 98 — but all of them together 152): a wave's
+// vector-memory operations retire IN ORDER, so the filter fragments of the next tap (an L2 hit) cannot be consumed before the HBM
+// loads of the patch staging issued ahead of them have landed; six taps out of nine wait for an HBM round trip.  Here ONE
+// 512-thread workgroup per CU gives each SIMD an MMA wave and a LOADER wave: waves 0-3 only load filter fragments (kSD taps ahead,
+// nothing else on their memory counter), read pixel fragments and issue MFMAs; waves 4-7 only stage patches (global -> registers
+// two chunks ahead -> lazy BatchNorm / ReLU / split -> LDS).  One barrier per chunk; all eight waves share the epilogue.
+#ifndef UWM_V2_ALDS
+#define UWM_V2_ALDS 1         // 8-wave kernel: 1 = the filter fragments of a chunk reach the MMA waves through LDS (loader waves' LDS-DMA, one copy per workgroup); 0 = every MMA wave loads them from L1 / L2 itself
+#endif
+typedef __attribute__((address_space(3))) void v2_lds_void;
+typedef const __attribute__((address_space(1))) void v2_gbl_void;
+#ifndef UWM_V2_SD
+#define UWM_V2_SD 4           // filter-fragment register sets of the MMA waves (prefetch distance UWM_V2_SD - 1 taps)
+#endif
+template <int NCF>
+__global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a) {
+  constexpr int kCo = 32 * NCF;
+  constexpr int kSD = UWM_V2_SD;
+  constexpr int dbg = UWM_F16V2_ABL;
+  constexpr bool kALds = UWM_V2_ALDS != 0;
+  constexpr int kAPieces = 9 * NCF * 2;                // 1-KB fragment planes of a chunk's filter block: [tap][fragment][hi | lo][64 lanes][16 B]
+  constexpr int kABuf = kAPieces * 1024;               // 36 864 bytes at NCF = 2
+
+  constexpr int kTrip = (kSD == 4 || kSD == 2) ? (kSD == 4 ? 4 : 2) : (kSD == 3 ? 1 : 0);      // chunks per loop trip: (9 * kTrip) % kSD == 0
+  static_assert(kTrip > 0 && (9 * kTrip) % kSD == 0, "UWM_V2_SD must be 2, 3 or 4");
+  extern __shared__ __attribute__((aligned(16))) char vsm[];      // [2][kVBuf] patch buffers; the epilogue's [4][64][kVQLd] floats
+  char* const asm_ = vsm + 2 * kVBuf;                  // [2][kABuf] behind the patch buffers (kALds)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_mma = wave < 4;
+  const int mw = wave & 3;                            // MMA wave index / loader wave index
+  const int ltid = tid & 255;                         // thread index inside its role
+  const int pcol = lane & 31, kh = lane >> 5;
+
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  unsigned tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tilesN = (a.Cout + kCo - 1) / kCo;
+  const int tilesW = a.Wo / kVW, tilesH = a.Ho / kVH;
+  // tile order inside an XCD's contiguous range: channel tile fastest (the channel tiles of one pixel tile share the patch in L2)
+  // while all their filter slices fit the XCD's 4-MB L2 beside the streams; else channel tile SLOWEST — an XCD then works on one
+  // filter slice (Ctot x 2304 bytes per 64 channels), which stays L2-resident, and streams the patches
+  int tn, tw, th, n;
+  if ((size_t)tilesN * a.Ctot * (36 * kCo) > (size_t)UWM_V2_COSLOW_BYTES) {
+    const int pixt = tilesW * tilesH * a.N;
+    tn = tile / pixt; tile -= tn * pixt;
+    tw = tile % tilesW; tile /= tilesW;
+    th = tile % tilesH; n = tile / tilesH;
   } else {
-    f4 rs = {0.f, 0.f, 0.f, 0.f}, bmu = rs, brs = rs, bia = rs, msc = {1.f, 1.f, 1.f, 1.f}, msh = rs;
-    if (cok) rs = *(const f4*)(rinv + co) * ixs;
-    if (bnb && cok) { bmu = *(const f4*)(a.bnb_mean + co); brs = *(const f4*)(a.bnb_rstd + co); }
-    if (a.bias && cok) bia = *(const f4*)(a.bias + co);
-    if (a.mscale && cok) { msc = *(const f4*)(a.mscale + co); msh = *(const f4*)(a.mshift + co); }
-#pragma unroll 4
-    for (int r = 0; r < 64 / kSub; ++r) {
-      const int p = r * kSub + sub;
-      const int ho = hb + (p >> 5), wo = w0 + (p & 31);
-      if (cok) {
-        const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
-        f4 v = *(const f4*)(R + p * kVQLd + cq * 4) * rs + bia;
-        if (a.addend) v += *(const f4*)(a.addend + o);
-        f4 yr = {0.f, 0.f, 0.f, 0.f};
-        if (a.mask) {
-          f4 mk = *(const f4*)(a.mask + o);
-          yr = mk;
-          if (a.mscale) mk = mk * msc + msh;
-          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    tn = tile % tilesN; tile /= tilesN;
+    tw = tile % tilesW; tile /= tilesW;
+    th = tile % tilesH; n = tile / tilesH;
+  }
+  const int n0 = tn * kCo, h0 = th * kVH, w0 = tw * kVW;
+  const int nF = a.wu_ncb;
+  const int nchunk = a.Ctot >> 4, nsteps = nchunk * 9;
+
+  float xs = 1.f;
+  if (a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
+
+  f16v acc[2][NCF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NCF; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (!is_mma) {
+    // ================= loader waves =================
+    int goff0[kVRounds], goff1[kVRounds];                // chunk-invariant source offsets of a round, per source of the concat
+    unsigned gflags = 0;
+    const bool has_x = ltid < kVUnits - (kVRounds - 1) * 256;
+#pragma unroll
+    for (int rd = 0; rd < kVRounds; ++rd) {
+      const int u = rd * 256 + ltid;
+      const bool act = u < kVUnits;
+      const int pp = act ? (u >> 2) : 0;
+      const int py = pp / kVPW, pxx = pp - py * kVPW;
+      const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
+      const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+      goff0[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
+      goff1[rd] = a.C0 < a.Ctot ? ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C : goff0[rd];
+      gflags |= (ok ? 1u : 0u) << rd;
+    }
+    struct Stage { f4 pv[kVRounds]; f4 sc, sh; float floor_; };
+    auto patch_load = [&](int cc, Stage& st) {
+      if (dbg & 8) return;
+      const int c = cc * 16;
+      const bool first = c < a.C0;
+      const Src& s = first ? a.s0 : a.s1;
+      const int cl = (first ? c : c - a.C0) + (ltid & 3) * 4;
+      if (s.scale != nullptr) { st.sc = *(const f4*)(s.scale + cl) * xs; st.sh = *(const f4*)(s.shift + cl) * xs; st.floor_ = s.relu ? 0.f : -65504.f; }
+      else { st.sc = (f4){xs, xs, xs, xs}; st.sh = (f4){0.f, 0.f, 0.f, 0.f}; st.floor_ = -65504.f; }
+      const float* sp = s.ptr + cl;
+#pragma unroll
+      for (int rd = 0; rd < kVRounds; ++rd) st.pv[rd] = *(const f4*)(sp + (first ? goff0[rd] : goff1[rd]));      // (every wave issues all six: the counted wait below relies on it; the offsets of inactive units are valid duplicates)
+    };
+    auto patch_store = [&](int buf, const Stage& st) {
+      if (dbg & 8) return;
+#pragma unroll
+      for (int rd = 0; rd < kVRounds; ++rd) {
+        if (rd == kVRounds - 1 && !has_x) break;
+        const bool ok = (gflags >> rd) & 1u;
+        const float lo_c = ok ? st.floor_ : 0.f, hi_c = ok ? 65504.f : 0.f;
+        const f4 raw = st.pv[rd];
+        f4 v;
+        v.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.x, st.sc.x, st.sh.x), lo_c, hi_c);
+        v.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.y, st.sc.y, st.sh.y), lo_c, hi_c);
+        v.z = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.z, st.sc.z, st.sh.z), lo_c, hi_c);
+        v.w = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.w, st.sc.w, st.sh.w), lo_c, hi_c);
+        u2 hi, lo;
+        split4(v, hi, lo);
+        const int u = rd * 256 + ltid;
+        char* d = vsm + buf * kVBuf + ((u >> 1) & 1) * kVPlane + (u >> 2) * 16 + (u & 1) * 8;
+        *(u2*)d = hi;
+        *(u2*)(d + 2 * kVPlane) = lo;
+      }
+    };
+    Stage sA, sB;
+    patch_load(0, sA);
+    patch_load(nchunk > 1 ? 1 : 0, sB);
+    patch_store(0, sA);
+    patch_load(nchunk > 2 ? 2 : nchunk - 1, sA);
+    __syncthreads();                                       // chunk 0 staged
+    // iteration c: store chunk c+1 (loaded two iterations ago), load chunk c+3 into the freed registers (plain loads only in these
+    // waves: hipcc then waits with counted vmcnt — beside an LDS-DMA it drains the whole queue at every use of a loaded register)
+    for (int cc = 0; cc < nchunk; cc += 2) {
+      {                                                    // c = cc: chunk c+1 sits in sB
+        if (cc + 1 < nchunk) patch_store(1, sB);
+        patch_load(cc + 3 < nchunk ? cc + 3 : nchunk - 1, sB);
+        __syncthreads();
+      }
+      {                                                    // c = cc + 1: chunk c+1 = cc+2 sits in sA
+        if (cc + 2 < nchunk) patch_store(0, sA);
+        patch_load(cc + 4 < nchunk ? cc + 4 : nchunk - 1, sA);
+        __syncthreads();
+      }
+    }
+
+  } else {
+    // ================= MMA waves =================
+    const _Float16* const wb = (const _Float16*)a.wu + (size_t)(n0 / 32) * 1024 + lane * 8;
+    auto w_load = [&](int t, h8 (&whi)[NCF], h8 (&wlo)[NCF]) {
+      if ((dbg & 2) && t >= kSD) return;
+      const _Float16* p = wb + (size_t)t * nF * 1024;
+#pragma unroll
+      for (int j = 0; j < NCF; ++j) { whi[j] = *(const h8*)(p + j * 1024); wlo[j] = *(const h8*)(p + j * 1024 + 512); }
+    };
+    // kALds: filter fragments of chunk cc -> LDS block cc & 1 by LDS-DMA, piece k (1 KB = one fragment plane, lane-linear on both
+    // sides) through MMA wave k & 3.  Issued at the START of chunk cc - 1: the MMA waves have no other vector-memory traffic, so the
+    // pieces have a whole chunk of MFMAs to land and the vmcnt(0) of the chunk's closing __syncthreads() finds them done
+    auto a_dma = [&](int cc) {
+      if (!kALds || (dbg & 2)) return;
+      char* const dst = asm_ + (cc & 1) * kABuf;
+#pragma unroll
+      for (int i = 0; i < (kAPieces + 3) / 4; ++i) {
+        const int k = i * 4 + mw;                          // (wave-uniform)
+        if (k < kAPieces) {
+          const int tap = k / (2 * NCF), rest = k % (2 * NCF);      // rest = fragment * 2 + plane
+          const _Float16* g = wb + ((size_t)(cc * 9 + tap) * nF) * 1024 + rest * 512;
+          __builtin_amdgcn_global_load_lds((v2_gbl_void*)g, (v2_lds_void*)(uintptr_t)(dst + k * 1024), 16, 0, 0);
         }
-        *(f4*)(a.out + o) = v;
-        if (a.bnb_y) yr = *(const f4*)(a.bnb_y + o);
-        ps_ += v; pq_ += bnb ? v * ((yr - bmu) * brs) : v * v;
       }
+    };
+    auto w_lds = [&](int c, int tap, h8 (&whi)[NCF], h8 (&wlo)[NCF]) {      // kALds: the same fragments out of the chunk's LDS block
+      if (dbg & 2) { whi[0] = (h8){1, 1, 1, 1, 1, 1, 1, 1}; wlo[0] = whi[0]; if (NCF > 1) { whi[NCF - 1] = whi[0]; wlo[NCF - 1] = whi[0]; } return; }
+      const char* p = asm_ + (c & 1) * kABuf + tap * (2 * NCF) * 1024 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < NCF; ++j) { whi[j] = *(const h8*)(p + (2 * j) * 1024); wlo[j] = *(const h8*)(p + (2 * j + 1) * 1024); }
+    };
+    const int pbase = kh * kVPlane + ((2 * mw) * kVPW + pcol) * 16;
+    auto x_load = [&](int tap, const char* pc, h8 (&xh)[2], h8 (&xl)[2]) {
+      const int off = ((tap / 3) * kVPW + tap % 3) * 16;
+      const char* pp = pc + pbase + off;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (dbg & 4) { xh[i] = (h8){1, 1, 1, 1, 1, 1, 1, 1}; xl[i] = xh[i]; continue; }
+        xh[i] = *(const h8*)(pp + i * kVPW * 16); xl[i] = *(const h8*)(pp + i * kVPW * 16 + 2 * kVPlane);
+      }
+    };
+    auto mma = [&](const h8 (&whi)[NCF], const h8 (&wlo)[NCF], const h8 (&xh)[2], const h8 (&xl)[2]) {
+      if (dbg & 1) { acc[0][0][0] += (float)xh[0][0] + (float)xl[1][1] + (float)whi[0][2] + (float)wlo[NCF - 1][3] + (float)xh[1][0]; return; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+    };
+    h8 w_hi[kSD][NCF], w_lo[kSD][NCF];
+    h8 x_h[2][2], x_l[2][2];
+    if (!kALds) {
+#pragma unroll
+      for (int d = 0; d < kSD - 1; ++d) w_load(d < nsteps ? d : nsteps - 1, w_hi[d], w_lo[d]);
+    } else a_dma(0);
+    __syncthreads();                                       // chunk 0 staged (patch and filter block)
+    // one chunk of the walk; `base` = (taps done so far) % kSD, a compile-time constant after unrolling
+    auto chunk = [&](int c, auto base_c) {
+      constexpr int base = decltype(base_c)::value;
+      const char* pc = vsm + (c & 1) * kVBuf;
+      if (kALds && c + 1 < nchunk) a_dma(c + 1);
+      x_load(0, pc, x_h[0], x_l[0]);
+      if (kALds) w_lds(c, 0, w_hi[0], w_lo[0]);
+#pragma unroll
+      for (int ks = 0; ks < 9; ++ks) {
+        const int t = c * 9 + ks;
+        const int xsn = ks & 1;
+        if (kALds) {                                       // both operands from LDS, one tap ahead
+          if (ks < 8) { w_lds(c, ks + 1, w_hi[xsn ^ 1], w_lo[xsn ^ 1]); x_load(ks + 1, pc, x_h[xsn ^ 1], x_l[xsn ^ 1]); }
+          __builtin_amdgcn_sched_barrier(0);
+          mma(w_hi[xsn], w_lo[xsn], x_h[xsn], x_l[xsn]);
+        } else {
+          const int tp = t + kSD - 1 < nsteps ? t + kSD - 1 : nsteps - 1;
+          const int ws = (base + ks) % kSD, wl = (base + ks + kSD - 1) % kSD;
+          w_load(tp, w_hi[wl], w_lo[wl]);
+          if (ks < 8) x_load(ks + 1, pc, x_h[xsn ^ 1], x_l[xsn ^ 1]);
+          __builtin_amdgcn_sched_barrier(0);               // (operand loads are ISSUED ahead of the MFMA block, not sunk behind it)
+          mma(w_hi[ws], w_lo[ws], x_h[xsn], x_l[xsn]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    };
+    int c = 0;
+    if (kTrip == 4) {
+      for (; c + 4 <= nchunk; c += 4) {
+        chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, 9 % kSD>{});
+        chunk(c + 2, std::integral_constant<int, 18 % kSD>{}); chunk(c + 3, std::integral_constant<int, 27 % kSD>{});
+      }
+      if (c < nchunk) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, 9 % kSD>{}); }      // (nchunk is even)
+    } else if (kTrip == 2) {
+      for (; c < nchunk; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, 9 % kSD>{}); }
+    } else {
+      for (; c < nchunk; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, 0>{}); }
     }
   }
-  if (do_stats) {
-    // the pixel sub-rows of a wave (xor kCQ .. 32) -> 4 waves through LDS -> fp64 atomics on one replica
+
+  // ---------------- epilogue (the 4-wave kernel's, spread over eight waves): an MMA wave's 64 px x kCo block goes through its LDS
+  // region; waves w and w + 4 finish its first and its second image row (the concat-split form sums 2 x 2 blocks across the two
+  // rows: the MMA waves do it alone)
+  if (is_mma) {
+    float* const Rw = (float*)vsm + mw * 64 * kVQLd;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float sv = ps_[e], qv = pq_[e];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int d = kCQ; d < 64; d <<= 1) { sv += __shfl_xor(sv, d); qv += __shfl_xor(qv, d); }
-      ps_[e] = sv; pq_[e] = qv;
-    }
-    __syncthreads();                             // every wave is done with its block
-    float* red = (float*)vsm;                    // [4 waves][64][2]
-    if (sub == 0) {
+      for (int j = 0; j < NCF; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { red[(wave * 64 + cq * 4 + e) * 2] = ps_[e]; red[(wave * 64 + cq * 4 + e) * 2 + 1] = pq_[e]; }
-    }
-    __syncthreads();
-    if (tid < kCo) {
-      const int c1 = n0 + tid;
-      if (c1 < stat_c) {
-        double sv = 0.0, qv = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { sv += (double)red[(w * 64 + tid) * 2]; qv += (double)red[(w * 64 + tid) * 2 + 1]; }
-        const size_t srep_off = a.srep > 1 ? (size_t)(blockIdx.x & (unsigned)(a.srep - 1)) * a.sstride : 0;
-        atomicAdd(a.ssum + srep_off + c1, sv);
-        atomicAdd(a.ssq + srep_off + c1, qv);
-      }
-    }
+        for (int q = 0; q < 4; ++q)
+          *(f4*)(Rw + (i * 32 + pcol) * kVQLd + j * 32 + q * 8 + kh * 4) = (f4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
   }
+  __syncthreads();
+  const float* const R = (const float*)vsm + mw * 64 * kVQLd;
+  f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
+  if (NCF == 2 && a.out_up != nullptr) { if (is_mma) v2_epilogue<NCF>(a, R, 0, 64, n, h0 + 2 * mw, w0, n0, lane, 1.f / xs, ps_, pq_); }
+  else v2_epilogue<NCF>(a, R, (wave >> 2) * 32, 32, n, h0 + 2 * mw, w0, n0, lane, 1.f / xs, ps_, pq_);
+  if (a.ssum != nullptr) v2_stats<NCF, 8>(a, (float*)vsm, ps_, pq_, n0, tid, lane, wave);
 }
 
 // 3x3 / stride 1 / pad 1 over whole 8 x 32-pixel tiles, 16-channel chunks in PAIRS on either side of a concat (the loop is
@@ -446,29 +751,51 @@ bool conv_f16x3v2_applicable(const ConvArgs& a) {
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
 }
 
-hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant) {      // variant: 0 auto | 4 = 64-channel tiles | 5 = 32-channel tiles
+hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant) {      // variant: 0 auto | 4 / 5 = 4-wave kernel, 64- / 32-channel tiles | 6 / 7 = 8-wave kernel, 64- / 32-channel tiles
   if (!conv_f16x3v2_applicable(a)) return hipErrorInvalidValue;
   if (a.out_up && (a.addend || a.mask || a.bias || a.bnb_y || (a.ssum && !a.bnb_mean) || (a.up_c0 < a.Cout && !a.out))) return hipErrorInvalidValue;
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum)) return hipErrorInvalidValue;
   const int tiles = a.N * (a.Ho / kVH) * (a.Wo / kVW);
   const size_t main_lds = (size_t)2 * kVBuf + (size_t)kVRounds * 256 * sizeof(int), q_lds = (size_t)4 * 64 * kVQLd * sizeof(float);
   const size_t lds = main_lds > q_lds ? main_lds : q_lds;
-  // 32-channel tiles: the 32-output layers, and (forward only, where nothing co-runs) launches whose 64-channel tiles cannot give
-  // every CU two workgroups
-  const long wgs64 = (long)route_N(a) * (a.Ho / kVH) * (a.Wo / kVW) * ((a.Cout + 63) / 64);
-  const bool fwd_alone = a.rmul == 1 && !a.xmax;
-  const bool narrow = variant == 5 || (variant == 0 && !a.out_up && ((a.Cout & 63) != 0 || (fwd_alone && wgs64 < 2L * device_cu_count())));
-  if (narrow) {
-    if (a.out_up) return hipErrorInvalidValue;
-    static DevOnce lds_attr1;
-    { hipError_t e = lds_attr1.set_max_lds((const void*)conv_f16x3v2_kernel<1>, lds); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<1>), dim3((unsigned)(tiles * (a.Cout / 32))), dim3(256), lds, st, a);
+  // which kernel (kernel-alone timings at 16 x 512^2, profiles/r04_*): 32-channel tiles -> the 8-wave kernel (128 -> 32 at 256^2: 260 us
+  // against 275 on the 4-wave kernel and 394 on conv_f16x3.hip's); 64-channel tiles -> the 4-wave kernel while the launch gives every
+  // CU two workgroups (they cover each other's prologue and epilogue: 64 -> 64 at 128^2 71 vs 85 us), the 8-wave kernel below that
+  // (256 -> 256 at 32^2: 56 vs 57-69 us)
+  int v = variant;
+  if (v == 0) {
+    const long wgs64 = (long)route_N(a) * (a.Ho / kVH) * (a.Wo / kVW) * ((a.Cout + 63) / 64);
+    if ((a.Cout & 63) != 0) v = 7;
+    else v = (wgs64 >= 2L * device_cu_count() || a.out_up) ? 4 : 6;
+  }
+  if ((v == 4 || v == 6) && (a.Cout & 63)) return hipErrorInvalidValue;
+  if ((v == 5 || v == 7) && a.out_up) return hipErrorInvalidValue;
+  const int ncf = (v == 4 || v == 6) ? 2 : 1;
+  const unsigned grid = (unsigned)(tiles * (a.Cout / (32 * ncf)));
+  if (v == 6 || v == 7) {
+    const size_t s_lds = UWM_V2_ALDS ? (size_t)2 * kVBuf + (size_t)2 * 9 * ncf * 2 * 1024 : 0;      // patch buffers + two filter-fragment blocks
+    const size_t lds8 = s_lds > q_lds ? s_lds : q_lds;
+    if (v == 7) {
+      static DevOnce lds_attr3;
+      { hipError_t e = lds_attr3.set_max_lds((const void*)conv_f16x3v2s_kernel<1>, lds8); if (e != hipSuccess) return e; }
+      UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2s_kernel<1>), dim3(grid), dim3(512), lds8, st, a);
+    } else {
+      static DevOnce lds_attr4;
+      { hipError_t e = lds_attr4.set_max_lds((const void*)conv_f16x3v2s_kernel<2>, lds8); if (e != hipSuccess) return e; }
+      UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2s_kernel<2>), dim3(grid), dim3(512), lds8, st, a);
+    }
     return hipGetLastError();
   }
-  if (a.Cout & 63) return hipErrorInvalidValue;
+  if (v == 5) {
+    static DevOnce lds_attr1;
+    { hipError_t e = lds_attr1.set_max_lds((const void*)conv_f16x3v2_kernel<1>, lds); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<1>), dim3(grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+  }
+  if (v != 4) return hipErrorInvalidValue;
   static DevOnce lds_attr2;
   { hipError_t e = lds_attr2.set_max_lds((const void*)conv_f16x3v2_kernel<2>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<2>), dim3((unsigned)(tiles * (a.Cout / 64))), dim3(256), lds, st, a);
+  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<2>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -357,7 +357,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
   if (cfg == 700) return launch_conv_up2(a, st);
   if (cfg >= 800 && cfg < 1000) return launch_conv_gemm(a, st, cfg - 800);
   if (cfg == 500) return launch_conv_head(a, st);
-  if ((cfg >= 600 && cfg <= 605) || (cfg < 0 && a.prec == 2)) return launch_conv_f16x3(a, st, cfg >= 600 ? cfg - 600 : 0);      // fp16x3 direct form: the bank behind a.wu is a conv_f16x3.hip one
+  if ((cfg >= 600 && cfg <= 607) || (cfg < 0 && a.prec == 2)) return launch_conv_f16x3(a, st, cfg >= 600 ? cfg - 600 : 0);      // fp16x3 direct form: the bank behind a.wu is a conv_f16x3.hip one
   if (cfg == 400) return launch_conv_wino_x3(a, st);
   if (cfg >= 300) return launch_conv_wino(a, st, cfg - 300);
   if (a.out_up) {                                                  // fused concat split: Winograd epilogues (and the sub-pixel dgrad of conv_up2.hip)

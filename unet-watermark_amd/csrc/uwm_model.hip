@@ -1596,8 +1596,9 @@ static int op_wino_prepare(ConvArgs& a, int mirror, hipStream_t st, bool x3 = fa
   return 0;
 }
 // fp16x3 bank for the op-level entry point (tests / timing): cfg 600
-static int op_f16x3_prepare(ConvArgs& a, hipStream_t st, int variant = 0) {
+static int op_f16x3_prepare(ConvArgs& a, hipStream_t st, int variant = 0, bool reuse = false) {
   static float* buf = nullptr; static size_t cap = 0;
+  static const float* last_w = nullptr; static int last_rows = 0, last_chans = 0, last_layout = -1;      // kernel timing (cfg + 1000): the bank of the previous call is reused when it matches
   if ((a.Ctot & 31) && !(a.Ctot == 16 && a.Cout <= 16)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs channels %% 32 == 0 (or the 16 -> 16 single-chunk layer)");
   const size_t need = f16x3_bank_floats(a.wrows, a.Ctot);
   if (need > cap) {
@@ -1610,7 +1611,8 @@ static int op_f16x3_prepare(ConvArgs& a, hipStream_t st, int variant = 0) {
   // bank layout: 601-603 force a conv_f16x3.hip kernel (layout 0), 604 / 605 a conv_f16x3v2.hip one (layout 1), 600 = what the model would take
   const int layout = variant >= 4 ? 1 : (variant == 0 && f16x3v2_shape(a.Ho, a.Wo, a.wrows, a.Ctot) && a.wrows == a.Cout ? 1 : 0);
   j.w = a.w; j.ut = buf; j.rows = a.wrows; j.chans = a.Ctot; j.Kpad = a.Kpad; j.mode = 0; j.src_rows = a.wrows; j.pad_ = layout;
-  LCHK(launch_f16x3_weights_multi(jobs, st));
+  if (!(reuse && last_w == a.w && last_rows == a.wrows && last_chans == a.Ctot && last_layout == layout)) LCHK(launch_f16x3_weights_multi(jobs, st));
+  last_w = a.w; last_rows = a.wrows; last_chans = a.Ctot; last_layout = layout;
   a.wu = buf; a.wu_layout = layout; a.wu_ncb = layout == 1 ? f16x3v2_nf(a.wrows) : f16x3_nj(a.wrows); a.wu_rinv_off = (int)f16x3_rinv_off(a.wrows, a.Ctot); a.prec = 2;
   return 0;
 }
@@ -1739,9 +1741,11 @@ int uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows,
     LCHK(launch_conv_stem_f16x3(a, (hipStream_t)stream));
     return 0;
   }
-  if (cfg >= 600 && cfg <= 605) {                     // 600 auto | 601 four-wave kernel | 602 eight-wave kernel | 603 four-wave, 32-channel tiles | 604 / 605 conv_f16x3v2 64- / 32-channel tiles
+  const bool reuse_bank = cfg >= 1600 && cfg <= 1607;      // 16xx = 6xx without re-packing the filter bank (kernel-only timing: the previous call must have been the same layer and layout)
+  if (reuse_bank) cfg -= 1000;
+  if (cfg >= 600 && cfg <= 607) {                     // 606 / 607: conv_f16x3v2 8-wave kernel; 600 auto | 601 four-wave kernel | 602 eight-wave kernel | 603 four-wave, 32-channel tiles | 604 / 605 conv_f16x3v2 64- / 32-channel tiles
     if (!op_wino_shape(a, kh, kw, stride, pad)) return fail("uwm_op_conv: cfg 600 (fp16x3) needs 3x3 s1 p1, Ho >= 8, Wo >= 16");
-    if (op_f16x3_prepare(a, (hipStream_t)stream, cfg - 600)) return 1;
+    if (op_f16x3_prepare(a, (hipStream_t)stream, cfg - 600, reuse_bank)) return 1;
   } else if (((cfg >= 300 && cfg < 500) || (cfg < 0 && winograd_mode() != 0)) && op_wino_shape(a, kh, kw, stride, pad)) {
     if (op_wino_prepare(a, 0, (hipStream_t)stream, cfg == 400)) return 1;
   } else if (cfg >= 300 && cfg < 500) return fail("uwm_op_conv: cfg 300 (Winograd) needs 3x3 s1 p1, channels %% 8 == 0, Ho >= 8, Wo >= 16");
