@@ -52,9 +52,9 @@ def test_config2_resnet34_512_bs2_vs_oracle(cuda, mode, fill, route):
     if mode == "f32":
         assert not any("f16x3" in k for k in kinds), kinds
     else:
-        assert {"conv_f16x3_kernel", "wgrad_f16x3_kernel", "conv_stem_f16x3_kernel"} <= kinds, kinds
+        assert {"wgrad_f16x3_kernel", "conv_stem_f16x3_kernel"} <= kinds and kinds & {"conv_f16x3_kernel", "conv_f16x3v2_kernel"}, kinds
         if route == 16:
-            assert "conv_f16x3s_kernel" in kinds, kinds          # layer3 / layer4 at bs16: the eight-wave kernel
+            assert kinds & {"conv_f16x3s_kernel", "conv_f16x3v2s_kernel"}, kinds          # layer3 / layer4 at bs16: an eight-wave kernel
 
 
 def test_config4_full_size_effb4_1024_bs4(cuda):

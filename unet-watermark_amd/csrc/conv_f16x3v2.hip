@@ -62,9 +62,13 @@ int f16x3v2_nf(int rows) { return f16x3v2_nf_(rows); }
 
 // shapes the second form takes: whole 8 x 32 tiles, 32-channel output fragments (the launcher and whoever packs the bank agree
 // through ConvArgs::wu_layout, which carries this function's verdict)
-bool f16x3v2_shape(int Ho, int Wo, int rows, int chans) {
+bool f16x3v2_shape(int Ho, int Wo, int rows, int chans, int dgrad) {
   static const bool off = dbg_flag("UWM_F16X3_V1");
-  return !off && (Wo % kVW) == 0 && (Ho % kVH) == 0 && (chans & 31) == 0 && rows >= 32 && (rows & 31) == 0;
+  static const int mode = dbg_int("UWM_V2_MODE", 1);      // experiments: 0 never | 1 32-row-fragment layers only | 2 + forward convolutions | 3 wherever the shape allows
+  if (off || mode == 0 || (Wo % kVW) != 0 || (Ho % kVH) != 0 || (chans & 31) != 0 || rows < 32 || (rows & 31) != 0) return false;
+  if (mode == 1) return (rows & 63) != 0;
+  if (mode == 2) return (rows & 63) != 0 || !dgrad;
+  return true;
 }
 
 __global__ __launch_bounds__(256) void f16x3v2_weights_multi_kernel(const WinoJobs jobs) {

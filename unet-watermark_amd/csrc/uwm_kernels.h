@@ -222,7 +222,7 @@ hipError_t launch_f16x3_weights_multi(const WinoJobs& jobs, hipStream_t st);    
 bool conv_f16x3_applicable(const ConvArgs& a);
 static inline __host__ __device__ size_t f16x3_rinv_off_floats(int rows, int chans) { return (size_t)(chans / 16) * 5 * (size_t)(((rows + 63) / 64) * 4) * 512; }
 // conv_f16x3v2.hip: the same arithmetic on v_mfma_f32_32x32x16_f16, 8 x 32-pixel tiles (bank layout 1)
-bool f16x3v2_shape(int Ho, int Wo, int rows, int chans);      // shapes it takes (whole tiles, 32-row fragments): decides the bank layout
+bool f16x3v2_shape(int Ho, int Wo, int rows, int chans, int dgrad);      // layers it takes (whole tiles, 32-row fragments; which of them: measured, see the function): decides the bank layout
 int f16x3v2_nf(int rows);
 hipError_t launch_f16x3v2_weights_multi(const WinoJobs& jobs, hipStream_t st);      // the layout-1 jobs of a job table (row scales already made)
 bool conv_f16x3v2_applicable(const ConvArgs& a);

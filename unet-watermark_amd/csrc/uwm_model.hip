@@ -543,7 +543,7 @@ static int f3_layout(const uwm_model* m, size_t ci, bool dgrad) {
   bool split = false;
   if (dgrad) { for (auto& d : m->dec) if (d.c1 == (int)ci) split = true; for (auto& nd : m->nodes) if (nd.c1 == (int)ci) split = true; }
   if (split && (rows & 63)) return 0;
-  return f16x3v2_shape(p.oh[ci], p.ow[ci], rows, chans) ? 1 : 0;
+  return f16x3v2_shape(p.oh[ci], p.ow[ci], rows, chans, dgrad ? 1 : 0) ? 1 : 0;
 }
 // everything the choice of a dgrad filter bank's FORM depends on (Winograd mode, precision mode, fp16x3 fill rule, routing batch):
 // a change between a forward and its backward re-packs the banks at the start of the backward
@@ -1609,7 +1609,7 @@ static int op_f16x3_prepare(ConvArgs& a, hipStream_t st, int variant = 0, bool r
   WinoJobs jobs; jobs.n = 1;
   WinoJob& j = jobs.j[0];
   // bank layout: 601-603 force a conv_f16x3.hip kernel (layout 0), 604 / 605 a conv_f16x3v2.hip one (layout 1), 600 = what the model would take
-  const int layout = variant >= 4 ? 1 : (variant == 0 && f16x3v2_shape(a.Ho, a.Wo, a.wrows, a.Ctot) && a.wrows == a.Cout ? 1 : 0);
+  const int layout = variant >= 4 ? 1 : (variant == 0 && f16x3v2_shape(a.Ho, a.Wo, a.wrows, a.Ctot, 0) && a.wrows == a.Cout ? 1 : 0);
   j.w = a.w; j.ut = buf; j.rows = a.wrows; j.chans = a.Ctot; j.Kpad = a.Kpad; j.mode = 0; j.src_rows = a.wrows; j.pad_ = layout;
   if (!(reuse && last_w == a.w && last_rows == a.wrows && last_chans == a.Ctot && last_layout == layout)) LCHK(launch_f16x3_weights_multi(jobs, st));
   last_w = a.w; last_rows = a.wrows; last_chans = a.Ctot; last_layout = layout;

@@ -258,7 +258,12 @@ class Unet(nn.Module):
         need = int(L.lib().uwm_routing_dump(self._h, None, 0, 0))
         buf = C.create_string_buffer(max(1, need))
         L.lib().uwm_routing_dump(self._h, buf, need, int(clear))
-        return [tuple(line.split(" ", 2)) for line in buf.value.decode().splitlines() if line]
+        out = []
+        for line in buf.value.decode().splitlines():
+            if line:
+                pas, layer, kern = line.split(" ", 2)
+                out.append((pas, layer, kern.strip("()")))       # (a templated kernel is written "(name<args>)" at its launch site)
+        return out
 
     def conv_flops(self, h: int, w: int):
         """Algorithmic conv FLOPs per image at h x w: (forward, forward+backward) — SURVEY.md 8(d)."""
