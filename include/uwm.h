@@ -49,7 +49,8 @@ enum { UWM_T_F32 = 0, UWM_T_I64 = 1, UWM_T_U8 = 2, UWM_T_I32 = 3 };          /* 
 enum { UWM_KIND_CONV_W = 0, UWM_KIND_BIAS = 1, UWM_KIND_BN_GAMMA = 2, UWM_KIND_BN_BETA = 3,
        UWM_KIND_BN_MEAN = 4, UWM_KIND_BN_VAR = 5 };
 enum { UWM_ARENA_PARAM = 0, UWM_ARENA_BUFFER = 1 };
-enum { UWM_PREC_F32 = 0, UWM_PREC_BF16X3 = 1, UWM_PREC_BF16X3_ALL = 2, UWM_PREC_F16X3 = 3, UWM_PREC_F16X3_ALL = 4 };       /* uwm_set_precision */
+enum { UWM_PREC_F32 = 0, UWM_PREC_BF16X3 = 1, UWM_PREC_BF16X3_ALL = 2, UWM_PREC_F16X3 = 3, UWM_PREC_F16X3_ALL = 4,
+       UWM_PREC_F16X1 = 5, UWM_PREC_F16X3_BWD2 = 6 };       /* uwm_set_precision */
 
 /* mirrors smp.Unet(encoder_name, encoder_depth=5, decoder_channels, in_channels, classes) */
 typedef struct {
@@ -205,7 +206,16 @@ int  uwm_get_winograd_mode(uwm_handle h);
  * v_mfma_f32_16x16x32_f16, direct-form convolution, fp32 accumulation; fp16's exponent range is covered by exact
  * power-of-two scaling of every filter row (and of a dgrad's dY).  fp32-class accuracy: it meets the fp32 mode's bars.
  *   UWM_PREC_F16X3       the FORWARD products of the 3x3 stride-1 layers with channels % 32 == 0
- *   UWM_PREC_F16X3_ALL   their data-gradient products as well (the layers whose dgrad has the plain epilogue) */
+ *   UWM_PREC_F16X3_ALL   their data-gradient and weight-gradient products as well
+ * Two REDUCED-precision modes on the same kernels (never the default, never bench.py's headline; reported under alt_modes):
+ *   UWM_PREC_F16X1       one product per tile, hi * hi' — plain fp16 products with fp32 accumulation, fp32 storage, BatchNorm and
+ *                        optimizer: the arithmetic of the reference's own GPU path (torch.autocast fp16 + GradScaler,
+ *                        /root/reference/src/train.py:75,89-98) with the exact power-of-two range scaling in place of a loss
+ *                        scaler.  Forward, dgrad and wgrad.  Logits differ from the fp32 CPU reference by 2e-2 (resnet18) to
+ *                        7e-2 (resnet34; tests/test_model_gpu.py, bench.py alt_modes): OUTSIDE BASELINE's 1e-3 bar.
+ *   UWM_PREC_F16X3_BWD2  forward as UWM_PREC_F16X3_ALL (logits identical, inside the bar); in the backward the gradient operand dY
+ *                        enters as ONE fp16 (two products per tile: dy_hi * w_hi + dy_hi * w_lo), i.e. gradients carry 11-bit dY
+ *                        against 22-bit weights / activations — still above the reference's GPU arithmetic. */
 int  uwm_set_precision(uwm_handle h, int mode);
 int  uwm_get_precision(uwm_handle h);
 /* The fp16x3 forward / dgrad kernels work in 16x16-pixel x 64-channel workgroups and are taken for launches of at least

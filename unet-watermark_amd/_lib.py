@@ -48,7 +48,7 @@ KIND_CONV_W, KIND_BIAS, KIND_BN_GAMMA, KIND_BN_BETA, KIND_BN_MEAN, KIND_BN_VAR =
 ARENA_PARAM, ARENA_BUFFER = 0, 1
 ENC = {"resnet18": 18, "resnet34": 34, "resnet50": 50, "efficientnet-b4": 104}
 ARCH = {"Unet": 0, "UnetPlusPlus": 1}
-PREC = {"f32": 0, "bf16x3": 1, "bf16x3_all": 2, "f16x3": 3, "f16x3_all": 4}
+PREC = {"f32": 0, "bf16x3": 1, "bf16x3_all": 2, "f16x3": 3, "f16x3_all": 4, "f16x1": 5, "f16x3_bwd2": 6}
 P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
 # every symbol include/uwm.h declares: (restype, argtypes)

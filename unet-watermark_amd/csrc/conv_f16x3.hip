@@ -220,7 +220,8 @@ __device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed
 // staging inside the loop, one patch buffer, a [64 px][20]-float epilogue block per wave — 26 KB of LDS and ~100 VGPRs: up to
 // six short-lived workgroups per CU cover each other's load latency (the fp32 conv_patch16 kernel is bound by its matrix pipe
 // there: 123 us of fp32 MFMAs against a 107-us HBM floor)
-template <int NJ>
+// NP = split products per tile (ConvArgs::nprod): 3 = hi*hi' + hi*lo' + lo*hi'; 2 = without the pixel operand's low half (hi*lo'); 1 = hi*hi' only
+template <int NJ, int NP = 3>
 __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   constexpr bool kOne = NJ == 1;                       // single-chunk form
   constexpr int kCo = 16 * NJ;                         // output channels per workgroup
@@ -352,14 +353,18 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 2)) void conv_f16x3_kernel(cons
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+    if (NP >= 3) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+    }
+    if (NP >= 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+    }
   };
 
   h8 wA_hi[NJ], wA_lo[NJ], wB_hi[NJ], wB_lo[NJ];
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 2)) void conv_f16x3_kernel(cons
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
         for (int q = 0; q < 4 * NJ; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NP, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
@@ -516,6 +521,7 @@ __global__ __launch_bounds__(256, (NJ == 1 ? 4 : 2)) void conv_f16x3_kernel(cons
 // MFMAs (same tiling), waves 4-7 only stage — chunk c+1 into the other buffer while chunk c is multiplied, with the global
 // loads of chunk c+2 already in flight in a second register set (two chunks of latency budget).  One barrier per chunk.
 // All eight waves share the epilogue (32 pixels x 64 channels each).
+template <int NP = 3>
 __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];      // [2][324 px][40 halfs]
 
@@ -648,14 +654,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3s_kernel(const ConvArgs a) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+      if (NP >= 3) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+      }
+      if (NP >= 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+      }
     };
     h8 wA_hi[4], wA_lo[4], wB_hi[4], wB_lo[4], xh[4], xl[4];
     w_load(0, wA_hi, wA_lo);
@@ -774,6 +784,20 @@ bool conv_f16x3_applicable(const ConvArgs& a) {
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
 }
 
+template <int NJ, int NP>
+static hipError_t launch_f3(const ConvArgs& a, hipStream_t st, dim3 grid, size_t lds) {
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3_kernel<NJ, NP>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<NJ, NP>), grid, dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+template <int NP>
+static hipError_t launch_f3s(const ConvArgs& a, hipStream_t st, dim3 grid, size_t lds) {
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3s_kernel<NP>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3s_kernel<NP>), grid, dim3(512), lds, st, a);
+  return hipGetLastError();
+}
 hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   if (a.wu_layout == 1) return launch_conv_f16x3v2(a, st, variant >= 4 ? variant : 0);      // the bank is a conv_f16x3v2.hip one
   if (variant >= 4) return hipErrorInvalidValue;
@@ -790,12 +814,11 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   // (layer1 89 vs 93 us, layer2 73 vs 77)
   static const bool force4 = dbg_flag("UWM_F16X3_4WAVE"), force8 = dbg_flag("UWM_F16X3_8WAVE");
   const long wgs = (long)route_N(a) * tilesH * tilesW * tilesN;      // (variant choice: ConvArgs::route_n)
+  const int np = (a.nprod >= 1 && a.nprod <= 3) ? a.nprod : 3;
   if (a.Ctot == 16) {                                     // one chunk, 16 outputs: the single-chunk form
     const size_t lds1 = (size_t)kFBuf * sizeof(_Float16);          // one patch buffer (25 920 B) >= the epilogue's 4 x 64 x 20 floats
-    static DevOnce lds_attr1;
-    { hipError_t e = lds_attr1.set_max_lds((const void*)conv_f16x3_kernel<1>, lds1); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<1>), dim3((unsigned)(a.N * tilesH * tilesW)), dim3(256), lds1, st, a);
-    return hipGetLastError();
+    return np == 3 ? launch_f3<1, 3>(a, st, dim3((unsigned)(a.N * tilesH * tilesW)), lds1)
+         : np == 2 ? launch_f3<1, 2>(a, st, dim3((unsigned)(a.N * tilesH * tilesW)), lds1) : launch_f3<1, 1>(a, st, dim3((unsigned)(a.N * tilesH * tilesW)), lds1);
   }
   const bool four = variant == 1 || variant == 3 || (variant != 2 && (force4 || (!force8 && wgs >= 2L * device_cu_count())));
   if (variant == 3 && a.out_up) return hipErrorInvalidValue;
@@ -805,21 +828,12 @@ hipError_t launch_conv_f16x3(const ConvArgs& a, hipStream_t st, int variant) {
   const bool fwd_alone = a.rmul == 1 && !a.xmax;
   const bool narrow = !a.out_up && (a.Cout <= 32 ? four : (fwd_alone && variant == 0 && wgs < device_cu_count()));
   if (variant == 3 || (variant == 0 && narrow)) {
-    static DevOnce lds_attr2;
-    { hipError_t e = lds_attr2.set_max_lds((const void*)conv_f16x3_kernel<2>, lds); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<2>), dim3((unsigned)(a.N * tilesH * tilesW * ((a.Cout + 31) / 32))), dim3(256), lds, st, a);
-    return hipGetLastError();
+    const dim3 g((unsigned)(a.N * tilesH * tilesW * ((a.Cout + 31) / 32)));
+    return np == 3 ? launch_f3<2, 3>(a, st, g, lds) : np == 2 ? launch_f3<2, 2>(a, st, g, lds) : launch_f3<2, 1>(a, st, g, lds);
   }
-  if (four) {
-    static DevOnce lds_attr;
-    { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3_kernel<4>, lds); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3_kernel<4>), dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(256), lds, st, a);
-    return hipGetLastError();
-  }
-  static DevOnce lds_attr_s;
-  { hipError_t e = lds_attr_s.set_max_lds((const void*)conv_f16x3s_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(42, a.flops, a.bytes, conv_f16x3s_kernel, dim3((unsigned)(a.N * tilesH * tilesW * tilesN)), dim3(512), lds, st, a);
-  return hipGetLastError();
+  const dim3 g((unsigned)(a.N * tilesH * tilesW * tilesN));
+  if (four) return np == 3 ? launch_f3<4, 3>(a, st, g, lds) : np == 2 ? launch_f3<4, 2>(a, st, g, lds) : launch_f3<4, 1>(a, st, g, lds);
+  return np == 3 ? launch_f3s<3>(a, st, g, lds) : np == 2 ? launch_f3s<2>(a, st, g, lds) : launch_f3s<1>(a, st, g, lds);
 }
 
 }  // namespace uwm

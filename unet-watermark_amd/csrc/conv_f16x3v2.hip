@@ -243,7 +243,8 @@ __device__ __forceinline__ void v2_stats(const ConvArgs& a, float* red, f4 ps_, 
 }
 
 // ---------------------------------------------------------------- main kernel
-template <int NCF>
+// NP = split products per tile (ConvArgs::nprod): 3 = hi*hi' + hi*lo' + lo*hi'; 2 = without the pixel operand's low half; 1 = hi*hi' only
+template <int NCF, int NP = 3>
 __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) {
   constexpr int kCo = 32 * NCF;                        // output channels per workgroup
   constexpr int kCQ = kCo / 4, kSub = 64 / kCQ;        // epilogue: lanes along the channel quads x pixel sub-rows
@@ -374,14 +375,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+    if (NP >= 3) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+    }
+    if (NP >= 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+    }
   };
 
   // filter-fragment ring: kAD register sets, the loads of tap t + kAD - 1 are issued while tap t is multiplied (9 taps per chunk:
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
         __builtin_amdgcn_sched_group_barrier(0x020, 2 * NCF, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-        for (int q = 0; q < 6 * NCF; ++q) {
+        for (int q = 0; q < 2 * NP * NCF; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
@@ -488,7 +493,7 @@ typedef const __attribute__((address_space(1))) void v2_gbl_void;
 #ifndef UWM_V2_SD
 #define UWM_V2_SD 4           // filter-fragment register sets of the MMA waves (prefetch distance UWM_V2_SD - 1 taps)
 #endif
-template <int NCF>
+template <int NCF, int NP = 3>
 __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a) {
   constexpr int kCo = 32 * NCF;
   constexpr int kSD = UWM_V2_SD;
@@ -667,14 +672,18 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xh[i], acc[i][j], 0, 0, 0);
+      if (NP >= 3) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi[j], xl[i], acc[i][j], 0, 0, 0);
+      }
+      if (NP >= 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
+      }
     };
     h8 w_hi[kSD][NCF], w_lo[kSD][NCF];
     h8 x_h[2][2], x_l[2][2];
@@ -755,6 +764,20 @@ bool conv_f16x3v2_applicable(const ConvArgs& a) {
          (size_t)a.N * a.s0.H * a.s0.W * a.s0.C < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W * a.s1.C < (1ull << 31);
 }
 
+template <int NCF, int NP>
+static hipError_t launch_v2(const ConvArgs& a, hipStream_t st, unsigned grid, size_t lds) {
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3v2_kernel<NCF, NP>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<NCF, NP>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+template <int NCF, int NP>
+static hipError_t launch_v2s(const ConvArgs& a, hipStream_t st, unsigned grid, size_t lds) {
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_f16x3v2s_kernel<NCF, NP>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2s_kernel<NCF, NP>), dim3(grid), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
 hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant) {      // variant: 0 auto | 4 / 5 = 4-wave kernel, 64- / 32-channel tiles | 6 / 7 = 8-wave kernel, 64- / 32-channel tiles
   if (!conv_f16x3v2_applicable(a)) return hipErrorInvalidValue;
   if (a.out_up && (a.addend || a.mask || a.bias || a.bnb_y || (a.ssum && !a.bnb_mean) || (a.up_c0 < a.Cout && !a.out))) return hipErrorInvalidValue;
@@ -776,31 +799,16 @@ hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant) {
   if ((v == 5 || v == 7) && a.out_up) return hipErrorInvalidValue;
   const int ncf = (v == 4 || v == 6) ? 2 : 1;
   const unsigned grid = (unsigned)(tiles * (a.Cout / (32 * ncf)));
+  const int np = (a.nprod >= 1 && a.nprod <= 3) ? a.nprod : 3;
   if (v == 6 || v == 7) {
     const size_t s_lds = UWM_V2_ALDS ? (size_t)2 * kVBuf + (size_t)2 * 9 * ncf * 2 * 1024 : 0;      // patch buffers + two filter-fragment blocks
     const size_t lds8 = s_lds > q_lds ? s_lds : q_lds;
-    if (v == 7) {
-      static DevOnce lds_attr3;
-      { hipError_t e = lds_attr3.set_max_lds((const void*)conv_f16x3v2s_kernel<1>, lds8); if (e != hipSuccess) return e; }
-      UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2s_kernel<1>), dim3(grid), dim3(512), lds8, st, a);
-    } else {
-      static DevOnce lds_attr4;
-      { hipError_t e = lds_attr4.set_max_lds((const void*)conv_f16x3v2s_kernel<2>, lds8); if (e != hipSuccess) return e; }
-      UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2s_kernel<2>), dim3(grid), dim3(512), lds8, st, a);
-    }
-    return hipGetLastError();
+    if (v == 7) return np == 3 ? launch_v2s<1, 3>(a, st, grid, lds8) : np == 2 ? launch_v2s<1, 2>(a, st, grid, lds8) : launch_v2s<1, 1>(a, st, grid, lds8);
+    return np == 3 ? launch_v2s<2, 3>(a, st, grid, lds8) : np == 2 ? launch_v2s<2, 2>(a, st, grid, lds8) : launch_v2s<2, 1>(a, st, grid, lds8);
   }
-  if (v == 5) {
-    static DevOnce lds_attr1;
-    { hipError_t e = lds_attr1.set_max_lds((const void*)conv_f16x3v2_kernel<1>, lds); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<1>), dim3(grid), dim3(256), lds, st, a);
-    return hipGetLastError();
-  }
+  if (v == 5) return np == 3 ? launch_v2<1, 3>(a, st, grid, lds) : np == 2 ? launch_v2<1, 2>(a, st, grid, lds) : launch_v2<1, 1>(a, st, grid, lds);
   if (v != 4) return hipErrorInvalidValue;
-  static DevOnce lds_attr2;
-  { hipError_t e = lds_attr2.set_max_lds((const void*)conv_f16x3v2_kernel<2>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(42, a.flops, a.bytes, (conv_f16x3v2_kernel<2>), dim3(grid), dim3(256), lds, st, a);
-  return hipGetLastError();
+  return np == 3 ? launch_v2<2, 3>(a, st, grid, lds) : np == 2 ? launch_v2<2, 2>(a, st, grid, lds) : launch_v2<2, 1>(a, st, grid, lds);
 }
 
 }  // namespace uwm

@@ -92,6 +92,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|input| (a dgrad's dY, written by bn_bwd_apply), or nullptr: the input is staged times the power of two that puts that maximum in [2^13, 2^14), undone in the epilogue
   int route_n;               // > 0: choose the kernel VARIANT as if the batch were route_n images (uwm_set_routing_batch: a small parity sample on the kernels the full batch takes); 0: N
+  int nprod;                 // prec 2: split products per tile — 0 / 3: hi*hi' + hi*lo' + lo*hi' (fp32-class); 2: the pixel operand (a dgrad's dY) as ONE fp16 (hi*hi' + lo_w*hi'); 1: hi*hi' only (plain fp16 products, the reference's autocast arithmetic)
   int wu_layout;             // prec 2: layout of the fp16x3 bank behind wu — 0: conv_f16x3.hip (tap pairs, 16-row fragments), 1: conv_f16x3v2.hip (taps, 32-row fragments); set by whoever packed the bank (f16x3v2_shape)
 };
 
@@ -131,6 +132,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
   ReduceQueue* rq;           // HOST pointer (never read on the device) or nullptr: queue the partial-sum reduce instead of launching it
   int cu_share;              // prec 2: 0 = one workgroup per CU; n = per n/4 of the CUs (3 when the launch runs beside the dependent chain: the rest stay free of its 768-thread workgroups)
   int route_n;               // as ConvArgs::route_n
+  int nprod;                 // prec 2: as ConvArgs::nprod (2: dY as one fp16: dy_hi*x_hi + dy_hi*x_lo)
 };
 
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on

@@ -524,14 +524,22 @@ static bool f3d_plain(const uwm_model* m, int ci) {
 // fp16x3 weight gradient: the map tiled by whole 4 x 32- or 8 x 16-pixel stages, 32-channel tiles on either side of the concat
 static bool f3_wgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
-  return p.prec == UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && cv.Cout >= 32 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP &&
+  return p.prec >= UWM_PREC_F16X3_ALL && cv.wino() && cv.bn >= 0 && cv.Cout >= 32 && (cv.CinP & 31) == 0 && (cv.c0 & 31) == 0 && cv.Kpad == 9 * cv.CinP &&
          (((p.ow[ci] % 32) == 0 && (p.oh[ci] % 4) == 0) || ((p.ow[ci] % 16) == 0 && (p.oh[ci] % 8) == 0)) && !dbg_flag("UWM_NO_F16X3_WGRAD");
 }
 static bool f3_dgrad_on(const uwm_model* m, size_t ci) {
   const ConvL& cv = m->convs[ci]; const Plan& p = m->plan;
-  if (p.prec != UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
+  if (p.prec < UWM_PREC_F16X3_ALL || !cv.f3_d() || cv.bn < 0 || !p.wino_ok(ci) || !f3d_plain(m, (int)ci)) return false;
   const long wgs = (long)(m->route_n > 0 ? m->route_n : p.N) * ((p.oh[ci] + 15) / 16) * ((p.ow[ci] + 15) / 16) * ((cv.CinP + 63) / 64);      // (stride 1: the input has the output's size)
   return wgs >= (m->f3_min_wgs > 0 ? m->f3_min_wgs : device_cu_count() / 2);
+}
+// split products per tile (ConvArgs::nprod / WgradArgs::nprod) under the handle's precision mode: f16x1 = hi*hi' everywhere;
+// f16x3_bwd2 = the backward's dY operand as ONE fp16 (two products), forward unchanged; the fp32-class modes: three
+static int f3_nprod(const uwm_model* m, bool backward) {
+  const int pm = m->plan.prec;
+  if (pm == UWM_PREC_F16X1) return 1;
+  if (pm == UWM_PREC_F16X3_BWD2 && backward) return 2;
+  return 3;
 }
 // layout of a layer's fp16x3 bank (ConvArgs::wu_layout): 1 = conv_f16x3v2.hip (32x32x16 MFMA, 8 x 32-pixel tiles) where the map is
 // tiled by whole tiles and the output rows by 32-row fragments (a decoder conv1 dgrad with the fused concat split: 64-row tiles)
@@ -604,7 +612,7 @@ static hipError_t run_conv_fwd(const Ctx& c, int ci, const Src& s0, const Src* s
       a.prec = 1;
     }
     if (f3_fwd_on(c.m, (size_t)ci)) {
-      a.prec = 2; a.wu_layout = f3_layout(c.m, (size_t)ci, false);
+      a.prec = 2; a.wu_layout = f3_layout(c.m, (size_t)ci, false); a.nprod = f3_nprod(c.m, false);
       a.wu_ncb = a.wu_layout == 1 ? f16x3v2_nf(cv.Cout) : f16x3_nj(cv.Cout); a.wu_rinv_off = (int)f16x3_rinv_off(cv.Cout, cv.CinP);
     }
   }
@@ -638,7 +646,7 @@ static hipError_t run_dgrad(const Ctx& c, int ci, const float* dy, int Ho, int W
     const int pm = c.m->plan.prec;
     if ((pm == UWM_PREC_BF16X3 || pm == UWM_PREC_BF16X3_ALL) && cv.x3_d()) a.prec = 1;
     if (f3_dgrad_on(c.m, (size_t)ci) && (!us || (us->C0 & 63) == 0)) {        // fp16x3 direct form: dY scaled by the power of two bn_bwd_apply's max|dy| calls for
-      a.prec = 2; a.wu_layout = f3_layout(c.m, (size_t)ci, true);
+      a.prec = 2; a.wu_layout = f3_layout(c.m, (size_t)ci, true); a.nprod = f3_nprod(c.m, true);
       a.wu_ncb = a.wu_layout == 1 ? f16x3v2_nf(cv.CinP) : f16x3_nj(cv.CinP); a.wu_rinv_off = (int)f16x3_rinv_off(cv.CinP, cv.CoutP);
       a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off());
     }
@@ -675,7 +683,7 @@ static hipError_t run_wgrad(const Ctx& c, int ci, const Src& s0, const Src* s1, 
   a.bytes = 4.0 * ((double)a.M * cv.CoutP + (double)c.N * s0.H * s0.W * s0.C + (s1 ? (double)c.N * s1->H * s1->W * s1->C : 0.0) +
                    (double)cv.Cout * cv.Kpad);
   a.wino = c.m->plan.wino_mode + 1; a.route_n = c.m->route_n;
-  if (f3_wgrad_on(c.m, (size_t)ci)) { a.prec = 2; a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off()); a.cu_share = (c.wst && c.wst != c.st) ? 3 : 0; }
+  if (f3_wgrad_on(c.m, (size_t)ci)) { a.prec = 2; a.nprod = f3_nprod(c.m, true); a.xmax = (const float*)c.D(c.m->bns[cv.bn].xmax_off()); a.cu_share = (c.wst && c.wst != c.st) ? 3 : 0; }
   // partial images of a split launch: the next free slice of the scratch; their reduce is queued and runs with the other layers'
   // in one launch (flush_reduces: when the scratch / queue fills up and at the end of every backward stage)
   static const bool no_defer = dbg_flag("UWM_NO_DEFER_REDUCE");
@@ -789,7 +797,7 @@ static int do_forward(uwm_model* m, const float* x, float* logits, float* ws, in
   const Plan& p = m->plan;
   Ctx c{m, ws, st, N};
   if (m->prec_from_env) {               // say once which arithmetic a process default switched on (a stray variable must not go unnoticed)
-    static const char* names[5] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all"};
+    static const char* names[7] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all", "f16x1", "f16x3_bwd2"};
     fprintf(stderr, "libuwm: precision mode %s for this handle comes from UWM_PRECISION (uwm_set_precision overrides it)\n", names[m->prec]);
     m->prec_from_env = false;
   }
@@ -1264,10 +1272,10 @@ int uwm_create(const uwm_unet_desc* desc, uwm_handle* out) {
   const char* e = getenv("UWM_SIDE_STREAM");
   m->use_side = e ? atoi(e) : 1;
   if (const char* pe = getenv("UWM_PRECISION")) {      // process default of the precision mode (like UWM_WINOGRAD): f32 | bf16x3 | bf16x3_all | f16x3 | f16x3_all or 0..4
-    static const char* names[5] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all"};
+    static const char* names[7] = {"f32", "bf16x3", "bf16x3_all", "f16x3", "f16x3_all", "f16x1", "f16x3_bwd2"};
     int found = -1;
-    for (int i = 0; i < 5; ++i) if (!strcmp(pe, names[i]) || (pe[0] == '0' + i && !pe[1])) found = i;
-    if (found < 0) { delete m; return fail("uwm_create: UWM_PRECISION=%s is not a precision mode (f32 | bf16x3 | bf16x3_all | f16x3 | f16x3_all or 0..4)", pe); }
+    for (int i = 0; i < 7; ++i) if (!strcmp(pe, names[i]) || (pe[0] == '0' + i && !pe[1])) found = i;
+    if (found < 0) { delete m; return fail("uwm_create: UWM_PRECISION=%s is not a precision mode (f32 | bf16x3 | bf16x3_all | f16x3 | f16x3_all | f16x1 | f16x3_bwd2 or 0..6)", pe); }
     m->prec = found; m->plan.prec = found; m->prec_from_env = found != UWM_PREC_F32;
   }
   if (const char* pf = getenv("UWM_F16X3_MIN_WGS")) m->f3_min_wgs = atoi(pf) > 0 ? atoi(pf) : 0;      // process default of uwm_set_precision_fill
@@ -1655,8 +1663,8 @@ int uwm_set_winograd_mode(uwm_handle h, int mode) {
 int uwm_get_winograd_mode(uwm_handle h) { return h ? h->wino_mode : -1; }
 int uwm_set_precision(uwm_handle h, int mode) {
   if (!h) return fail("uwm_set_precision: null handle");
-  if (mode < UWM_PREC_F32 || mode > UWM_PREC_F16X3_ALL)
-    return fail("uwm_set_precision: mode must be UWM_PREC_F32 (0), UWM_PREC_BF16X3 (1), UWM_PREC_BF16X3_ALL (2), UWM_PREC_F16X3 (3) or UWM_PREC_F16X3_ALL (4), got %d", mode);
+  if (mode < UWM_PREC_F32 || mode > UWM_PREC_F16X3_BWD2)
+    return fail("uwm_set_precision: mode must be UWM_PREC_F32 (0), UWM_PREC_BF16X3 (1), UWM_PREC_BF16X3_ALL (2), UWM_PREC_F16X3 (3), UWM_PREC_F16X3_ALL (4), UWM_PREC_F16X1 (5) or UWM_PREC_F16X3_BWD2 (6), got %d", mode);
   h->prec = mode; h->plan.prec = mode;          // the workspace layout does not depend on the mode (the banks have one size)
   return 0;
 }

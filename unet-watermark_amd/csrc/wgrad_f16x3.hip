@@ -57,7 +57,8 @@ __device__ __forceinline__ h8 tr_pair(const char* base, int o0, int o1) {      /
   return __builtin_bit_cast(h8, v);
 }
 
-template <int WX>
+// NP = split products per tile (WgradArgs::nprod): 3 = dy_hi*x_hi + dy_hi*x_lo + dy_lo*x_hi; 2 = dY as ONE fp16 (no dy_lo*x_hi); 1 = dy_hi*x_hi only
+template <int WX, int NP = 3>
 __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, int stages_per_split, int nstages) {
   constexpr int kWR = WG16<WX>::kWR, kWX = WX, kWPW = WG16<WX>::kWPW, kWPH = WG16<WX>::kWPH, kWStage = WG16<WX>::kWStage, kWXRounds = WG16<WX>::kWXRounds;
   constexpr int kKS = 4, kRK = 32 / WX;                // k-steps (32 pixels) per stage; image rows per k-step (1 / 2)
@@ -234,11 +235,11 @@ __global__ __launch_bounds__(768, 1) void wgrad_f16x3_kernel(const WgradArgs a, 
           if (UWM_WG16_ABL & 1) { if (it < 9) { acc[0][it][0] += (float)xh[it % 3][0] + (float)xl[it % 3][1]; acc[1][it][1] += (float)ah[1][2] + (float)al[0][3]; } continue; }
           const int pt = it - 1, ps = (it + 2) % 3, cs = it % 3;
           if (it < 9) acc[0][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], xh[cs], acc[0][it], 0, 0, 0);
-          if (it >= 1) acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], xl[ps], acc[0][pt], 0, 0, 0);
+          if (NP >= 2 && it >= 1) acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], xl[ps], acc[0][pt], 0, 0, 0);
           if (it < 9) acc[1][it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], xh[cs], acc[1][it], 0, 0, 0);
-          if (it >= 1) acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], xl[ps], acc[1][pt], 0, 0, 0);
-          if (it >= 1) acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], xh[ps], acc[0][pt], 0, 0, 0);
-          if (it >= 1) acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], xh[ps], acc[1][pt], 0, 0, 0);
+          if (NP >= 2 && it >= 1) acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], xl[ps], acc[1][pt], 0, 0, 0);
+          if (NP >= 3 && it >= 1) acc[0][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], xh[ps], acc[0][pt], 0, 0, 0);
+          if (NP >= 3 && it >= 1) acc[1][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], xh[ps], acc[1][pt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -279,13 +280,18 @@ bool wgrad_f16x3_applicable(const WgradArgs& a) {
          (size_t)a.N * a.s0.H * a.s0.W < (1ull << 31) && (size_t)a.N * a.s1.H * a.s1.W < (1ull << 31) && (size_t)8 * a.Wo * a.Cout < (1ull << 31);
 }
 
-template <int WX>
-static hipError_t launch_wg16(WgradArgs& a, hipStream_t st, int pairs, int sps, int nstages) {
+template <int WX, int NP>
+static hipError_t launch_wg16p(WgradArgs& a, hipStream_t st, int pairs, int sps, int nstages) {
   const size_t lds = (size_t)2 * WG16<WX>::kWStage;
   static DevOnce lds_attr;
-  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_f16x3_kernel<WX>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(43, a.flops, a.bytes, (wgrad_f16x3_kernel<WX>), dim3((unsigned)(pairs * a.nsplit)), dim3(768), lds, st, a, sps, nstages);
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_f16x3_kernel<WX, NP>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(43, a.flops, a.bytes, (wgrad_f16x3_kernel<WX, NP>), dim3((unsigned)(pairs * a.nsplit)), dim3(768), lds, st, a, sps, nstages);
   return hipGetLastError();
+}
+template <int WX>
+static hipError_t launch_wg16(WgradArgs& a, hipStream_t st, int pairs, int sps, int nstages) {
+  const int np = (a.nprod >= 1 && a.nprod <= 3) ? a.nprod : 3;
+  return np == 3 ? launch_wg16p<WX, 3>(a, st, pairs, sps, nstages) : np == 2 ? launch_wg16p<WX, 2>(a, st, pairs, sps, nstages) : launch_wg16p<WX, 1>(a, st, pairs, sps, nstages);
 }
 
 hipError_t launch_wgrad_f16x3(const WgradArgs& a0, hipStream_t st) {
