@@ -192,6 +192,66 @@ def collect_prof(L, steps):
     return ents
 
 
+def ddp_verdict(local, real_step, stages, world, rank, dev):
+    """The collective half of validate_ddp, free of the model so that tests/test_ddp_gloo.py can drive it over gloo with fabricated
+    arenas at world 8: `local` = this rank's local gradient arena; `real_step()` runs the step under test and returns (exchanged
+    gradient arena, parameter arena).  Checks, bucket by bucket ([begin, end) ranges `stages`): the exchanged gradients equal ONE plain
+    SUM all-reduce of the local ones within fp32 summation-order noise and are bit-identical across ranks (int64 checksums of the
+    raw bits, all-gathered); the parameters afterwards are bit-identical across ranks; the ranks' local gradients differ when
+    world > 1.  A failure on ANY rank prints the evidence and exits 3 on EVERY rank (the verdict is all-reduced first, so no rank is
+    left waiting in a collective).  Returns (rows, local |g|_1 per rank, parameters identical)."""
+    import torch
+    import torch.distributed as dist
+    expect = local.clone()
+    dist.all_reduce(expect, op=dist.ReduceOp.SUM)
+    lsum = torch.tensor([float(local.double().abs().sum())], dtype=torch.float64, device=dev)
+    lall = [torch.zeros_like(lsum) for _ in range(world)]
+    dist.all_gather(lall, lsum)
+    lvals = [float(v) for v in lall]
+    got, params = real_step()
+    bits = got.view(torch.int32).to(torch.int64)
+    rows, problems = [], []
+    for k, (b, e) in enumerate(stages):
+        if e <= b:
+            continue
+        ck = torch.stack([bits[b:e].sum(), (bits[b:e] * (torch.arange(e - b, device=dev) % 251 + 1)).sum()])
+        allck = [torch.zeros_like(ck) for _ in range(world)]
+        dist.all_gather(allck, ck)
+        same = all(torch.equal(allck[0], c_) for c_ in allck)
+        scale = float(expect[b:e].abs().max())
+        err = float((got[b:e] - expect[b:e]).abs().max())
+        ok_val = err <= 2e-5 * max(scale, 1e-30) + 1e-12
+        rows.append({"bucket": k, "floats": e - b, "bit_identical_across_ranks": bool(same),
+                     "max_abs_diff_vs_single_allreduce": float(f"{err:.3e}"), "max_abs": float(f"{scale:.3e}")})
+        if not same:
+            problems.append(f"bucket {k}: gradient bits differ across ranks after the all-reduce")
+        if not ok_val:
+            problems.append(f"bucket {k}: bucketed all-reduce differs from the single all-reduce of the local gradients by {err:.3e} (max {scale:.3e})")
+        if not scale > 0:
+            problems.append(f"bucket {k}: all-zero gradient")
+    if world > 1 and len(set(lvals)) == 1:
+        problems.append(f"local gradients are identical on every rank (|g|_1 = {lvals[0]}): the ranks are not training on rank-distinct data")
+    # parameters after the first optimizer step
+    pbits = params.view(torch.int32).to(torch.int64)
+    pck = torch.stack([pbits.sum(), (pbits * (torch.arange(pbits.numel(), device=dev) % 251 + 1)).sum()])
+    pall = [torch.zeros_like(pck) for _ in range(world)]
+    dist.all_gather(pall, pck)
+    psame = all(torch.equal(pall[0], c_) for c_ in pall)
+    if not psame:
+        problems.append("parameters differ across ranks after the first optimizer step")
+    bad = torch.tensor([1.0 if problems else 0.0], device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if float(bad) > 0:
+        if problems:
+            print(json.dumps({"ddp_check": "FAILED", "rank": rank, "problems": problems, "buckets": rows}), file=sys.stderr, flush=True)
+        if dev.type == "cuda":
+            dist.barrier(device_ids=[dev.index])
+        else:
+            dist.barrier()
+        sys.exit(3)
+    return rows, lvals, psame
+
+
 def validate_ddp(trainer, model, x, t, world, rank, dev):
     """Self-validation of the data-parallel exchange, run once before the warm-up (nobody can watch an 8-GPU run):
     (1) every rank's local gradient arena (one backward, no collective) is SUM-all-reduced in ONE plain collective = the
@@ -221,55 +281,14 @@ def validate_ddp(trainer, model, x, t, world, rank, dev):
     m._backward_raw(trainer._dl, 0, nst)
     torch.cuda.synchronize(dev)
     local = m.flat_grads().clone()
-    expect = local.clone()
-    dist.all_reduce(expect, op=dist.ReduceOp.SUM)
-    lsum = torch.tensor([float(local.double().abs().sum())], dtype=torch.float64, device=dev)
-    lall = [torch.zeros_like(lsum) for _ in range(world)]
-    dist.all_gather(lall, lsum)
-    lvals = [float(v) for v in lall]
     # running statistics moved in (1): put every rank back on rank 0's buffers so (2) starts from replicas, as a run does
     dist.broadcast(m._buffer_arena, src=0)
     # (2) the real step
-    trainer.step(x, t)
-    torch.cuda.synchronize(dev)
-    got = m.flat_grads()
-    bits = got.view(torch.int32).to(torch.int64)
-    rows, problems = [], []
-    for k, (b, e) in enumerate(m.stages):
-        if e <= b:
-            continue
-        ck = torch.stack([bits[b:e].sum(), (bits[b:e] * (torch.arange(e - b, device=dev) % 251 + 1)).sum()])
-        allck = [torch.zeros_like(ck) for _ in range(world)]
-        dist.all_gather(allck, ck)
-        same = all(torch.equal(allck[0], c_) for c_ in allck)
-        scale = float(expect[b:e].abs().max())
-        err = float((got[b:e] - expect[b:e]).abs().max())
-        ok_val = err <= 2e-5 * max(scale, 1e-30) + 1e-12
-        rows.append({"bucket": k, "floats": e - b, "bit_identical_across_ranks": bool(same),
-                     "max_abs_diff_vs_single_allreduce": float(f"{err:.3e}"), "max_abs": float(f"{scale:.3e}")})
-        if not same:
-            problems.append(f"bucket {k}: gradient bits differ across ranks after the all-reduce")
-        if not ok_val:
-            problems.append(f"bucket {k}: bucketed all-reduce differs from the single all-reduce of the local gradients by {err:.3e} (max {scale:.3e})")
-        if not scale > 0:
-            problems.append(f"bucket {k}: all-zero gradient")
-    if world > 1 and len(set(lvals)) == 1:
-        problems.append(f"local gradients are identical on every rank (|g|_1 = {lvals[0]}): the ranks are not training on rank-distinct data")
-    # (3) parameters after the first optimizer step
-    pbits = m.flat_parameters().view(torch.int32).to(torch.int64)
-    pck = torch.stack([pbits.sum(), (pbits * (torch.arange(pbits.numel(), device=dev) % 251 + 1)).sum()])
-    pall = [torch.zeros_like(pck) for _ in range(world)]
-    dist.all_gather(pall, pck)
-    psame = all(torch.equal(pall[0], c_) for c_ in pall)
-    if not psame:
-        problems.append("parameters differ across ranks after the first optimizer step")
-    bad = torch.tensor([1.0 if problems else 0.0], device=dev)
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-    if float(bad) > 0:
-        if problems:
-            print(json.dumps({"ddp_check": "FAILED", "rank": rank, "problems": problems, "buckets": rows}), file=sys.stderr, flush=True)
-        dist.barrier(device_ids=[dev.index])
-        sys.exit(3)
+    def real_step():
+        trainer.step(x, t)
+        torch.cuda.synchronize(dev)
+        return m.flat_grads(), m.flat_parameters()
+    rows, lvals, psame = ddp_verdict(local, real_step, m.stages, world, rank, dev)
     m.flat_parameters().copy_(snap[0]); m._buffer_arena.copy_(snap[1]); m._nbt_arena.copy_(snap[2])
     for b_ in (trainer.opt._bufs or []):
         b_.zero_()
