@@ -29,9 +29,14 @@ alias = {"wgrad_patch_kernel<64,32>": "wgrad_patch_kernel<64>", "conv_wino_x3_ke
 for k in sorted(dur, key=lambda k: -dur[k])[:16]:
     fe = fa[k].get("FETCH_SIZE", 0) / max(1, fn.get(k, 1)) * 1024; wr = wa[k].get("WRITE_SIZE", 0) / max(1, wn.get(k, 1)) * 1024
     gui = ma[k].get("GRBM_GUI_ACTIVE", 0); busy = ma[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
-    rows.append(dict(kernel=k, launches=cnt[k], avg_us=round(dur[k] / cnt[k], 1), fetch_bytes_raw=int(fe), fetch_bytes_x2=int(2 * fe),
-                     write_bytes=int(wr), mfma_busy_frac=round(busy / (gui / 8 * 1024), 3) if gui else None,
-                     clock_GHz=round(gui / 8 / (dur[k] * 1e3), 2) if dur[k] else None))
+    # GRBM_GUI_ACTIVE / 8 / duration reads high on short dispatches (the counter window is wider than the kernel: bn_finalize came out
+    # at 6.8 GHz) — MI355X_MICROARCH.md: "reads high on dispatches shorter than about 0.3 ms".  The clock and the busy fraction derived
+    # from it are printed only for kernels whose average launch is >= 20 us; below that both are null.
+    avg_us = dur[k] / cnt[k]
+    trust = avg_us >= 20.0
+    rows.append(dict(kernel=k, launches=cnt[k], avg_us=round(avg_us, 1), fetch_bytes_raw=int(fe), fetch_bytes_x2=int(2 * fe),
+                     write_bytes=int(wr), mfma_busy_frac=round(busy / (gui / 8 * 1024), 3) if (gui and trust) else None,
+                     clock_GHz=round(gui / 8 / (dur[k] * 1e3), 2) if (dur[k] and trust) else None))
     traffic[alias.get(k, k)] = {"hbm_bytes_per_launch": int(2 * fe + wr), "fetch_bytes_per_launch": int(2 * fe), "write_bytes_per_launch": int(wr), "launches": cnt[k]}
 json.dump(rows, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 json.dump({"source": f"profiles/{tag}_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; FETCH_SIZE x2 (gfx950), per launch",
