@@ -163,7 +163,8 @@ def source_sha256() -> str:
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "unet-watermark_amd", "csrc", "*.hip")) +
-                   glob.glob(os.path.join(ROOT, "unet-watermark_amd", "csrc", "*.h")) + [os.path.join(ROOT, "include", "uwm.h")])
+                   glob.glob(os.path.join(ROOT, "unet-watermark_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "unet-watermark_amd", "csrc", "*.inc")) +
+                   [os.path.join(ROOT, "include", "uwm.h")])
     for f in files:
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

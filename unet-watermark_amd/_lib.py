@@ -123,7 +123,7 @@ _lib = None
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/*.hip for gfx950 into libuwm.so (hipcc cross-compiles without a GPU)."""
     srcs = [_CSRC / s for s in SOURCES]
-    hdrs = [_CSRC / "uwm_kernels.h", _PKG_DIR.parent / "include" / "uwm.h"]
+    hdrs = [_CSRC / "uwm_kernels.h", _PKG_DIR.parent / "include" / "uwm.h"] + sorted(_CSRC.glob("*.inc"))
     if LIB_PATH.exists() and not force:
         newest = max(p.stat().st_mtime for p in srcs + hdrs)
         if LIB_PATH.stat().st_mtime >= newest:
