@@ -284,6 +284,7 @@ typedef struct {
  * kernel; 700 sub-pixel kernel for a 3x3 over a nearest-x2 upsampled 32-channel source with 16 outputs (conv_up2.hip);
  * 800 (+64 | +128 = channel tile) persistent LDS-DMA GEMM for 1x1 / stride-1 layers with Cin % 32 == 0 (conv_gemm.hip)
  * (tests / timing). */
+int  uwm_op_set_igemm_f16x3(int on);   /* tests / kernel timing: uwm_op_conv / uwm_op_dgrad launches that end on the implicit GEMM (stride 2, 1x1) use its fp16x3 split-product form (what the model does for the stride-2 layers in the fp16x3 precision modes) */
 int  uwm_op_conv(const uwm_src* s0, const uwm_src* s1, const float* w, int wrows, int Kpad, int kh, int kw, int stride,
                  int pad, int N, int Cout, const float* bias, float* y, double* stats, int cfg, uwm_stream stream);
 /* dx[N][H][W][Cin] = conv_transpose(dy[N][Ho][Wo][Cout], wd) (+addend, *relu-mask) ; wd [Cin][KpadD] */

@@ -400,6 +400,36 @@ def test_eval_forward_and_batch_independence(cuda):
     assert torch.equal(out, singles)
 
 
+def test_fp16x3_batch_independence_needs_a_pinned_routing(cuda):
+    """In the fp16x3 modes the kernel VARIANT of a layer (4-wave / 8-wave / 32-channel tiles, fp16x3 vs Winograd under the fill
+    rule) follows the launch size, so under the DEFAULT rule an image's logits may depend on the batch it rides in.
+    Pinning the routing — uwm_set_routing_batch (every size-dependent choice made for a fixed batch) or the fill threshold at 1 as
+    WatermarkPredictor does — makes a batch of 8 equal eight batch-1 calls bit for bit; README / INTEGRATION say so."""
+    import unet_watermark_amd as U
+    from oracle import unet_oracle as O
+    m, _ = _pair("resnet34", dev=cuda)
+    xs, _ = O.synthetic_batch(4, 256, 256, seed=3)
+    m.train()
+    with torch.no_grad():
+        for i in range(2):
+            m(xs.to(cuda) + 0.1 * i)                      # non-trivial running statistics
+    m.eval()
+    x, _ = O.synthetic_batch(8, 256, 256, seed=11)
+    x = x.to(cuda)
+    for kw in (dict(min_workgroups=0, routing_batch=16), dict(min_workgroups=1, routing_batch=0)):
+        m.set_precision("f16x3", **kw)
+        m.routing(enable=True)
+        with torch.no_grad():
+            out = m(x)
+            kinds8 = {k for _, _, k in m.routing()}
+            singles = torch.cat([m(x[i:i + 1]) for i in range(8)], 0)
+            kinds1 = {k for _, _, k in m.routing()}
+        assert kinds8 == kinds1 and any("f16x3" in k for k in kinds8), (kw, kinds8 ^ kinds1)
+        assert torch.equal(out, singles), kw
+    m.routing(enable=False)
+    m.set_precision("f32", min_workgroups=0, routing_batch=0)
+
+
 @pytest.mark.parametrize("tdtype", [torch.int64, torch.uint8, torch.float32])
 @pytest.mark.parametrize("wd,wb", [(1.0, 0.0), (0.0, 1.0), (0.3, 0.7)])
 def test_loss_values_and_gradients(cuda, tdtype, wd, wb):

@@ -810,6 +810,73 @@ def test_conv_f16x3_error_vs_fp64_and_range(cuda):
         assert errs["f16x3"] < bound and errs["f16x3"] < 5e-5, (xmag, wmag, errs)
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 64, 128, 32, 32, 3, 2, 1),    # layer2.0.conv1: 3x3 stride 2
+    (2, 64, 128, 32, 32, 1, 2, 0),    # downsample 1x1 stride 2
+    (1, 128, 256, 16, 24, 3, 2, 1),   # layer3.0.conv1, ragged pixel tiles
+    (3, 256, 512, 8, 8, 1, 2, 0),     # layer4 downsample
+])
+def test_igemm_f16x3_stride2_layers(cuda, shape):
+    """The stride-2 layers of the ResNet encoders (3x3 / stride 2, 1x1 / stride 2) and their dgrads on the implicit GEMM with
+    fp16x3 split products (ConvArgs::ig16 — conv_igemm_kernel<..., F16 = true>; the model takes it for these layers in the fp16x3
+    precision modes): forward with a lazy BatchNorm + ReLU source and statistics, dgrad with addend + ReLU mask and a dY as tiny
+    as a real Dice gradient (scaled through max|dY|), held against fp64 convolutions within 4x the exact-fp32 kernel's own error."""
+    L = lib()
+    n, cin, cout, h, w, k, st, p = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    sc = torch.rand(cin, generator=g) + 0.5; sc[::5] *= -1
+    sh = torch.randn(cin, generator=g) * 0.2
+    act = torch.relu(x * sc[:, None, None] + sh[:, None, None])
+    ref = F.conv2d(act.double(), wt.double(), None, st, p)
+    ho, wo = ref.shape[-2:]
+    xd = nhwc(x).to(cuda); scd, shd = sc.to(cuda), sh.to(cuda)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(cuda)
+    errs = {}
+    for name, on in (("f32", 0), ("f16x3", 1)):
+        L.lib().uwm_op_set_igemm_f16x3(on)
+        try:
+            y = torch.empty(n, ho, wo, cout, device=cuda)
+            stats = torch.zeros(2 * cout, dtype=torch.float64, device=cuda)
+            s0 = src(xd, scd, shd, relu=1)
+            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), cout, kpad, k, k, st, p, n, cout, None, P(y), P(stats), -1, stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib().uwm_op_set_igemm_f16x3(0)
+        d = (nchw(y.cpu()).double() - ref).abs()
+        errs[name] = float((d / ref.abs().amax((0, 2, 3), keepdim=True)).max())
+        assert torch.allclose(stats[:cout].cpu(), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+    assert errs["f16x3"] < 4 * errs["f32"] + 1e-7 and errs["f16x3"] < 2e-5, errs
+    # ---- dgrad (transposed gather by output-pixel parity classes), dY ~ 1e-6
+    xg = torch.randn(n, cin, h, w, generator=g).double().requires_grad_()
+    yg = F.conv2d(xg, wt.double(), None, st, p)
+    dy = torch.randn(yg.shape, generator=g) * 1e-6
+    yg.backward(dy.double())
+    coutp = rup(cout, 4)
+    kpadd = rup(k * k * coutp, 32)
+    wd = torch.empty(cin, kpadd, device=cuda)
+    L.check(L.lib().uwm_op_pack_dgrad(P(wp), cout, kpad, k * k, cin, P(wd), kpadd, coutp, stream()))
+    dyd = nhwc(dy).to(cuda)
+    addend = torch.randn(n, h, w, cin, generator=g) * 1e-6
+    maskt = torch.randn(n, h, w, cin, generator=g)
+    add_d, mask_d = addend.to(cuda), maskt.to(cuda)
+    ref_dx = (xg.grad.permute(0, 2, 3, 1) + addend.double()) * (maskt > 0)
+    derr = {}
+    for name, on in (("f32", 0), ("f16x3", 1)):
+        L.lib().uwm_op_set_igemm_f16x3(on)
+        try:
+            dx = torch.empty(n, h, w, cin, device=cuda)
+            L.check(L.lib().uwm_op_dgrad(P(dyd), n, ho, wo, coutp, P(wd), cin, kpadd, k, k, st, p, h, w, P(add_d), P(mask_d), None, None,
+                                         P(dx), stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib().uwm_op_set_igemm_f16x3(0)
+        derr[name] = float((dx.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max())
+    assert derr["f16x3"] < 4 * derr["f32"] + 1e-7 and derr["f16x3"] < 2e-5, derr
+
+
 def test_conv_f16x3_upsample_concat(cuda):
     """decoder conv1 on the fp16x3 kernel: cat(nearest_x2(d), skip), both sources lazy, concat boundary on a 16-channel chunk."""
     L = lib()

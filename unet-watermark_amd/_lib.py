@@ -105,6 +105,7 @@ SIGNATURES = {
     "uwm_prof_collect": (I, [C.POINTER(C.c_double), I]),
     "uwm_prof_class_name": (C.c_char_p, [I]),
     "uwm_debug_lookup": (I, [P, C.c_char_p, C.POINTER(L), C.POINTER(L)]),
+    "uwm_op_set_igemm_f16x3": (I, [I]),
     "uwm_op_conv": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, P, P, P, I, P]),
     "uwm_op_dgrad": (I, [P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P]),
     "uwm_op_wgrad": (I, [C.POINTER(uwm_src), C.POINTER(uwm_src), P, I, I, I, I, I, I, I, I, I, I, P, I, P]),

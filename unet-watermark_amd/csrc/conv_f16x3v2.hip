@@ -490,6 +490,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
 #endif
 typedef __attribute__((address_space(3))) void v2_lds_void;
 typedef const __attribute__((address_space(1))) void v2_gbl_void;
+#ifndef UWM_V2_LS
+#define UWM_V2_LS 2           // 8-wave kernel: register stages of the loader waves (chunks of load latency budget)
+#endif
 #ifndef UWM_V2_SD
 #define UWM_V2_SD 4           // filter-fragment register sets of the MMA waves (prefetch distance UWM_V2_SD - 1 taps)
 #endif
@@ -604,27 +607,29 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
         *(u2*)(d + 2 * kVPlane) = lo;
       }
     };
-    Stage sA, sB;
-    patch_load(0, sA);
-    patch_load(nchunk > 1 ? 1 : 0, sB);
-    patch_store(0, sA);
-    patch_load(nchunk > 2 ? 2 : nchunk - 1, sA);
+    // kLS register stages: chunk c+1 is stored while chunk c is multiplied, its loads were issued kLS - 1 iterations earlier
+    // (UWM_V2_LS = 2: two chunks of latency budget; 3: three)
+    constexpr int kLS = UWM_V2_LS;
+    Stage st[kLS];
+#pragma unroll
+    for (int k = 0; k < kLS; ++k) patch_load(k < nchunk ? k : nchunk - 1, st[k]);
+    patch_store(0, st[0]);
+    patch_load(kLS < nchunk ? kLS : nchunk - 1, st[0]);
     __syncthreads();                                       // chunk 0 staged
-    // iteration c: store chunk c+1 (loaded two iterations ago), load chunk c+3 into the freed registers (plain loads only in these
-    // waves: hipcc then waits with counted vmcnt — beside an LDS-DMA it drains the whole queue at every use of a loaded register)
-    for (int cc = 0; cc < nchunk; cc += 2) {
-      {                                                    // c = cc: chunk c+1 sits in sB
-        if (cc + 1 < nchunk) patch_store(1, sB);
-        patch_load(cc + 3 < nchunk ? cc + 3 : nchunk - 1, sB);
-        __syncthreads();
-      }
-      {                                                    // c = cc + 1: chunk c+1 = cc+2 sits in sA
-        if (cc + 2 < nchunk) patch_store(0, sA);
-        patch_load(cc + 4 < nchunk ? cc + 4 : nchunk - 1, sA);
-        __syncthreads();
+    // iteration c: store chunk c+1, load chunk c+1+kLS into the freed registers (plain loads only in these waves: hipcc then waits
+    // with counted vmcnt — beside an LDS-DMA it drains the whole queue at every use of a loaded register)
+    for (int cc = 0; cc < nchunk; cc += kLS) {
+#pragma unroll
+      for (int k = 0; k < kLS; ++k) {
+        const int c = cc + k;
+        if (c < nchunk) {                                  // (uniform: every wave of the workgroup meets the same nchunk barriers)
+          Stage& sg = st[(k + 1) % kLS];
+          if (c + 1 < nchunk) patch_store((c + 1) & 1, sg);
+          patch_load(c + 1 + kLS < nchunk ? c + 1 + kLS : nchunk - 1, sg);
+          __syncthreads();
+        }
       }
     }
-
   } else {
     // ================= MMA waves =================
     const _Float16* const wb = (const _Float16*)a.wu + (size_t)(n0 / 32) * 1024 + lane * 8;

@@ -32,7 +32,15 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
 // PC = stride-2 dgrad by output-pixel parity class (class 2*pc_h + pc_w = 3 - blockIdx.y: the four-tap class of a 3x3 is dispatched first): a workgroup covers only the pixels
 // (2i + pc_h, 2j + pc_w) and walk only the taps that reach an input pixel from that class (1, 2, 2 or 4 of the
 // nine; pc_taps lists them) — the plain transposed gather spends 3/4 of its MFMAs on taps its pixels cannot use.
-template <int BM, int BN, int WM, int WN, bool PC = false>
+// F16 (round 4) = the fp16x3 arithmetic of conv_f16x3.hip on this kernel's tiles: every staged fp32 value is split into hi + lo fp16
+// halves on its way into LDS (a row keeps its 128 bytes: 32 hi halfs | 32 lo halfs, 16-byte slots XOR-swizzled as before), a
+// 32-deep chunk is ONE k-step of v_mfma_f32_16x16x32_f16 and a product is hi*hi' + hi*lo' + lo*hi' — 3 MFMAs of 16 cycles where
+// the fp32 form issues 8 of 32.  Range: weights times 2^12 (kaiming-scale weights land near 2^8; |w| < 16 cannot overflow, smaller
+// ones keep their low half normal), a dgrad's dY times the power of two that puts max|dY| into [2^13, 2^14) (ConvArgs::xmax),
+// activations as they are, clamped to +-65504; undone on the accumulator (exact powers of two).
+constexpr float kIgWScale = 4096.f;
+typedef _Float16 ig_h8 __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int WM, int WN, bool PC = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int MI = BM / WM / 16;      // 16-pixel MFMA tiles per wave
   constexpr int NI = BN / WN / 16;      // 16-channel MFMA tiles per wave
@@ -80,6 +88,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+  float xs = 1.f;                                      // F16: power-of-two scale of a dgrad's dY
+  if (F16 && a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
 
   f4 xr[XR], wr[WR], tsc, tsh;
   unsigned xvalid = 0; int trelu = 0; bool thas = false;
@@ -125,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   };
 
+  const float xs_ = xs;
   auto store_chunk = [&](int buf) {
     float* xs = Xs + buf * BM * 32;
     float* ws = Ws + buf * BN * 32;
@@ -137,11 +153,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         if (!((xvalid >> i) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
       }
       const int row = r0 + 32 * i;
+      if (F16) {          // hi halfs of k = 4 unit .. +3 -> bytes [8 unit, 8 unit + 8) of the row's hi half, lo halfs -> the same place in the lo half
+        uwm_u2 hi, lo;
+        const float sc = xs_;
+        uwm_split4(__builtin_amdgcn_fmed3f(v.x * sc, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y * sc, -65504.f, 65504.f),
+                   __builtin_amdgcn_fmed3f(v.z * sc, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w * sc, -65504.f, 65504.f), hi, lo);
+        char* rb = (char*)(xs + row * 32);
+        const int sw = (row >> 1) & 7;
+        *(uwm_u2*)(rb + (((unit >> 1) ^ sw) << 4) + (unit & 1) * 8) = hi;
+        *(uwm_u2*)(rb + ((((unit >> 1) + 4) ^ sw) << 4) + (unit & 1) * 8) = lo;
+      } else
       *(f4*)(xs + row * 32 + ((unit ^ ((row >> 1) & 7)) << 2)) = v;
     }
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
       const int row = r0 + 32 * i;
+      if (F16) {
+        if (BN >= 32 || r0 < BN) {
+          uwm_u2 hi, lo;
+          const f4 w4 = wr[i] * kIgWScale;
+          uwm_split4(__builtin_amdgcn_fmed3f(w4.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(w4.y, -65504.f, 65504.f),
+                     __builtin_amdgcn_fmed3f(w4.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(w4.w, -65504.f, 65504.f), hi, lo);
+          char* rb = (char*)(ws + row * 32);
+          const int sw = (row >> 1) & 7;
+          *(uwm_u2*)(rb + (((unit >> 1) ^ sw) << 4) + (unit & 1) * 8) = hi;
+          *(uwm_u2*)(rb + ((((unit >> 1) + 4) ^ sw) << 4) + (unit & 1) * 8) = lo;
+        }
+      } else
       if (BN >= 32 || r0 < BN) *(f4*)(ws + row * 32 + ((unit ^ ((row >> 1) & 7)) << 2)) = wr[i];
     }
   };
@@ -159,6 +197,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     load_chunk(kc + 1 < nk ? kc + 1 : kc);     // unconditional prefetch: single-basic-block loop body
     const float* xs = Xs + cur * BM * 32;
     const float* ws = Ws + cur * BN * 32;
+    if (F16) {
+      // lane (row lrow, k group lq): 8 consecutive k = one 16-byte slot of the row's hi half, the same slot + 4 of its lo half
+      ig_h8 xh[MI], xl[MI], wh[NI], wl[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = (wm * MI + i) * 16 + lrow;
+        const char* rb = (const char*)(xs + row * 32);
+        const int sw = (row >> 1) & 7;
+        xh[i] = *(const ig_h8*)(rb + ((lq ^ sw) << 4)); xl[i] = *(const ig_h8*)(rb + (((lq + 4) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = (wn * NI + j) * 16 + lrow;
+        const char* rb = (const char*)(ws + row * 32);
+        const int sw = (row >> 1) & 7;
+        wh[j] = *(const ig_h8*)(rb + ((lq ^ sw) << 4)); wl[j] = *(const ig_h8*)(rb + (((lq + 4) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+    } else
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
       f4 xf[MI], wf[NI];
@@ -196,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // fused BatchNorm-backward sums (uwm_kernels.h ConvArgs::bnb_*): second sum = v * yhat of the mask tensor (round 2: the 1x1 and
   // stride-2 dgrads of the Bottleneck encoder feed bn2 / bn1 this way)
   const bool bnb = a.bnb_mean != nullptr;
+  const float unscale = 1.f / (kIgWScale * xs);        // (F16: exact powers of two)
   f4 bmu[NI], brs[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -217,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int co = n0 + (wn * NI + j) * 16 + lq * 4;
       if (mv && co < a.Cout) {
         f4 v = acc[i][j];
+        if (F16) v = v * unscale;
         const size_t o = (size_t)m * a.Cout + co;
         if (a.bias) v += *(const f4*)(a.bias + co);
         if (a.addend) v += *(const f4*)(a.addend + o);
@@ -270,14 +340,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
+template <int BM, int BN, int WM, int WN, bool F16>
+static hipError_t launch_cfg_(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
   static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
-  { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN, false, F16>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, false, F16>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
   return hipGetLastError();
+}
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st, int cls) {
+  return a.ig16 ? launch_cfg_<BM, BN, WM, WN, true>(a, st, cls) : launch_cfg_<BM, BN, WM, WN, false>(a, st, cls);
 }
 
 // stride-2 dgrad as four parity-class launches (see the PC template flag)
@@ -285,13 +359,19 @@ bool conv_s2_dgrad_applicable(const ConvArgs& a) {
   return a.rmul == -1 && a.sdiv == 2 && a.smul == 1 && (a.ntaps == 9 || a.ntaps == 1) && (a.Ctot & 31) == 0 && a.C0 == a.Ctot &&
          (a.Ho & 1) == 0 && (a.Wo & 1) == 0 && a.s0.up == 0;
 }
+template <int BM, int BN, int WM, int WN, bool F16>
+static hipError_t launch_s2_dgrad_(const ConvArgs& a0, hipStream_t st, int cls);
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_s2_dgrad(const ConvArgs& a0, hipStream_t st, int cls) {
+  return a0.ig16 ? launch_s2_dgrad_<BM, BN, WM, WN, true>(a0, st, cls) : launch_s2_dgrad_<BM, BN, WM, WN, false>(a0, st, cls);
+}
+template <int BM, int BN, int WM, int WN, bool F16>
+static hipError_t launch_s2_dgrad_(const ConvArgs& a0, hipStream_t st, int cls) {
   const int Mg = a0.N * (a0.Ho >> 1) * (a0.Wo >> 1);
   const int tilesM = (Mg + BM - 1) / BM, tilesN = (a0.Cout + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
   static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
-  { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN, true>, lds); if (e != hipSuccess) return e; }
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN, true, F16>, lds); if (e != hipSuccess) return e; }
   ConvArgs a = a0;
   for (int pc = 0; pc < 4; ++pc) {
     a.pc_taps[pc] = 0; a.pc_ntaps[pc] = 0;
@@ -299,7 +379,7 @@ static hipError_t launch_s2_dgrad(const ConvArgs& a0, hipStream_t st, int cls) {
       for (int s = 0; s < a.kw; ++s)         // tap (r, s) reaches an input pixel iff (ho - r + off) and (wo - s + off) are even
         if (((((pc >> 1) - r + a.off) | ((pc & 1) - s + a.off)) & 1) == 0) { a.pc_taps[pc] |= (unsigned)(r * a.kw + s) << (4 * a.pc_ntaps[pc]); ++a.pc_ntaps[pc]; }
   }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, true, F16>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

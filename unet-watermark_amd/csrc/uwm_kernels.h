@@ -92,6 +92,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|input| (a dgrad's dY, written by bn_bwd_apply), or nullptr: the input is staged times the power of two that puts that maximum in [2^13, 2^14), undone in the epilogue
   int route_n;               // > 0: choose the kernel VARIANT as if the batch were route_n images (uwm_set_routing_batch: a small parity sample on the kernels the full batch takes); 0: N
+  int ig16;                  // implicit-GEMM launches (conv_igemm.hip: stride-2 3x3, 1x1 stride 2, their dgrads): 1 = fp16x3 split products on v_mfma_f32_16x16x32_f16 (operands split while staging, weights times 2^12, a dgrad's dY by xmax); 0 = exact fp32
   int nprod;                 // prec 2: split products per tile — 0 / 3: hi*hi' + hi*lo' + lo*hi' (fp32-class); 2: the pixel operand (a dgrad's dY) as ONE fp16 (hi*hi' + lo_w*hi'); 1: hi*hi' only (plain fp16 products, the reference's autocast arithmetic)
   int wu_layout;             // prec 2: layout of the fp16x3 bank behind wu — 0: conv_f16x3.hip (tap pairs, 16-row fragments), 1: conv_f16x3v2.hip (taps, 32-row fragments); set by whoever packed the bank (f16x3v2_shape)
 };
@@ -99,6 +100,27 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
 // batch the VARIANT choice of a launcher is made for (ConvArgs::route_n / WgradArgs::route_n; grids always use the real N)
 template <class A> static inline int route_N(const A& a) { return a.route_n > 0 ? a.route_n : a.N; }
 template <class A> static inline long route_M(const A& a) { return a.N > 0 ? (long)a.M / a.N * route_N(a) : (long)a.M; }
+
+#if defined(__HIPCC__)
+// Split of four fp32 values into hi / lo fp16 halves (the fp16x3 operand form): hi = rn_f16(x) (v_cvt_pk_f16_f32, two values per
+// instruction), lo = rn_f16(x - hi) as ONE v_fma_mix{lo,hi}_f16 per value — fma(hi_as_f32, -1.0, x) rounded to fp16 into one half
+// of the destination, the fp16 operand selected out of the packed register by op_sel (exact: an fp32 value minus its fp16 rounding
+// is representable in fp32).  Results as packed pairs: {x, y}, {z, w}.
+typedef unsigned uwm_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void uwm_split4(float x0, float x1, float x2, float x3, uwm_u2& hi, uwm_u2& lo) {
+  typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+  const h2_ a = {(_Float16)x0, (_Float16)x1}, b = {(_Float16)x2, (_Float16)x3};
+  hi.x = __builtin_bit_cast(unsigned, a); hi.y = __builtin_bit_cast(unsigned, b);
+  unsigned l0, l1;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l0) : "v"(hi.x), "v"(x0), "v"(x1));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(l1) : "v"(hi.y), "v"(x2), "v"(x3));
+  lo.x = l0; lo.y = l1;
+}
+#endif
 
 // Deferred partial-sum reduces.  A split weight-gradient launch leaves `nsplit` dW-shaped partial images in scratch; adding them
 // up (fixed order) used to be one small launch behind every wgrad (37 per resnet34 step, each 3x slower beside the other
