@@ -37,7 +37,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 #ifndef UWM_F16V2_ABL
-#define UWM_F16V2_ABL 0       // compile-time timing ablations: 1 no MFMA, 2 no filter loads, 4 no pixel-fragment LDS reads, 8 no patch loads / stores; 0 in the product build
+#define UWM_F16V2_ABL 0       // compile-time timing ablations: 1 no MFMA, 2 no filter loads, 4 no pixel-fragment LDS reads, 8 no patch loads / stores, (8-wave kernel) 16 no global patch loads, 32 no patch conversion / LDS stores, 64 no filter DMA (LDS reads stay); 0 in the product build
 #endif
 #ifndef UWM_V2_COSLOW_BYTES
 #define UWM_V2_COSLOW_BYTES (2u << 20)      // filter bytes of all channel tiles beyond which the tile walk keeps one channel tile per XCD
@@ -490,6 +490,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
 #endif
 typedef __attribute__((address_space(3))) void v2_lds_void;
 typedef const __attribute__((address_space(1))) void v2_gbl_void;
+#ifndef UWM_V2_W128
+#define UWM_V2_W128 1         // 8-wave kernel: loader units of 8 channels, 16-byte LDS stores (0: 4 channels, 8-byte stores)
+#endif
 #ifndef UWM_V2_LS
 #define UWM_V2_LS 2           // 8-wave kernel: register stages of the loader waves (chunks of load latency budget)
 #endif
@@ -557,6 +560,71 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
 
   if (!is_mma) {
     // ================= loader waves =================
+#if UWM_V2_W128
+    // unit u = rd * 256 + ltid -> pixel u >> 1 of the 10 x 34 patch, channel OCTET u & 1 (= ltid & 1): two 16-byte loads, and the
+    // eight hi / lo halfs leave as ONE 16-byte LDS store each (half the store instructions of the quad form: the LDS stores of the
+    // loader waves, not their loads or their arithmetic, are what the MMA waves feel — profiles/r04_t_*)
+    constexpr int kUnits8 = kVPP * 2, kR8 = (kUnits8 + 255) / 256;      // 680 units, 3 rounds (the last one: 168)
+    int goff0[kR8], goff1[kR8];
+    unsigned gflags = 0;
+    const bool has_x = ltid < kUnits8 - (kR8 - 1) * 256;
+#pragma unroll
+    for (int rd = 0; rd < kR8; ++rd) {
+      const int u = rd * 256 + ltid;
+      const bool act = u < kUnits8;
+      const int pp = act ? (u >> 1) : 0;
+      const int py = pp / kVPW, pxx = pp - py * kVPW;
+      const int hl = h0 - 1 + py, wl = w0 - 1 + pxx;
+      const bool ok = act && hl >= 0 && hl < a.Hl && wl >= 0 && wl < a.Wl;
+      const int hc = min(max(hl, 0), a.Hl - 1), wc = min(max(wl, 0), a.Wl - 1);
+      goff0[rd] = ((n * a.s0.H + (hc >> a.s0.up)) * a.s0.W + (wc >> a.s0.up)) * a.s0.C;
+      goff1[rd] = a.C0 < a.Ctot ? ((n * a.s1.H + (hc >> a.s1.up)) * a.s1.W + (wc >> a.s1.up)) * a.s1.C : goff0[rd];
+      gflags |= (ok ? 1u : 0u) << rd;
+    }
+    struct Stage { f4 pv[kR8][2]; f4 sc[2], sh[2]; float floor_; };
+    auto patch_load = [&](int cc, Stage& st) {
+      if (dbg & 8) return;
+      const int c = cc * 16;
+      const bool first = c < a.C0;
+      const Src& s = first ? a.s0 : a.s1;
+      const int cl = (first ? c : c - a.C0) + (ltid & 1) * 8;
+      if (s.scale != nullptr) {
+        st.sc[0] = *(const f4*)(s.scale + cl) * xs; st.sc[1] = *(const f4*)(s.scale + cl + 4) * xs;
+        st.sh[0] = *(const f4*)(s.shift + cl) * xs; st.sh[1] = *(const f4*)(s.shift + cl + 4) * xs; st.floor_ = s.relu ? 0.f : -65504.f;
+      } else { st.sc[0] = st.sc[1] = (f4){xs, xs, xs, xs}; st.sh[0] = st.sh[1] = (f4){0.f, 0.f, 0.f, 0.f}; st.floor_ = -65504.f; }
+      const float* sp = s.ptr + cl;
+#pragma unroll
+      for (int rd = 0; rd < kR8; ++rd) {
+        const float* q = sp + (first ? goff0[rd] : goff1[rd]);
+        st.pv[rd][0] = *(const f4*)q; st.pv[rd][1] = *(const f4*)(q + 4);
+      }
+    };
+    auto patch_store = [&](int buf, const Stage& st) {
+      if (dbg & 8) return;
+#pragma unroll
+      for (int rd = 0; rd < kR8; ++rd) {
+        if (rd == kR8 - 1 && !has_x) break;
+        const bool ok = (gflags >> rd) & 1u;
+        const float lo_c = ok ? st.floor_ : 0.f, hi_c = ok ? 65504.f : 0.f;
+        u2 hi[2], lo[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const f4 raw = st.pv[rd][e];
+          f4 v;
+          v.x = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.x, st.sc[e].x, st.sh[e].x), lo_c, hi_c);
+          v.y = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.y, st.sc[e].y, st.sh[e].y), lo_c, hi_c);
+          v.z = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.z, st.sc[e].z, st.sh[e].z), lo_c, hi_c);
+          v.w = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.w, st.sc[e].w, st.sh[e].w), lo_c, hi_c);
+          split4(v, hi[e], lo[e]);
+        }
+        const int u = rd * 256 + ltid;
+        char* d = vsm + buf * kVBuf + (u & 1) * kVPlane + (u >> 1) * 16;
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        *(u4*)d = (u4){hi[0].x, hi[0].y, hi[1].x, hi[1].y};
+        *(u4*)(d + 2 * kVPlane) = (u4){lo[0].x, lo[0].y, lo[1].x, lo[1].y};
+      }
+    };
+#else
     int goff0[kVRounds], goff1[kVRounds];                // chunk-invariant source offsets of a round, per source of the concat
     unsigned gflags = 0;
     const bool has_x = ltid < kVUnits - (kVRounds - 1) * 256;
@@ -576,6 +644,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
     struct Stage { f4 pv[kVRounds]; f4 sc, sh; float floor_; };
     auto patch_load = [&](int cc, Stage& st) {
       if (dbg & 8) return;
+      if ((dbg & 16) && cc > 2) return;
       const int c = cc * 16;
       const bool first = c < a.C0;
       const Src& s = first ? a.s0 : a.s1;
@@ -588,6 +657,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
     };
     auto patch_store = [&](int buf, const Stage& st) {
       if (dbg & 8) return;
+      if ((dbg & 32) && buf >= 0) { asm volatile("" :: "v"(st.pv[0].x), "v"(st.pv[5].w)); return; }
 #pragma unroll
       for (int rd = 0; rd < kVRounds; ++rd) {
         if (rd == kVRounds - 1 && !has_x) break;
@@ -600,13 +670,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
         v.z = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.z, st.sc.z, st.sh.z), lo_c, hi_c);
         v.w = __builtin_amdgcn_fmed3f(__builtin_fmaf(raw.w, st.sc.w, st.sh.w), lo_c, hi_c);
         u2 hi, lo;
-        split4(v, hi, lo);
+        if (dbg & 256) { hi = (u2){__builtin_bit_cast(unsigned, raw.x), __builtin_bit_cast(unsigned, raw.y)}; lo = (u2){__builtin_bit_cast(unsigned, raw.z), __builtin_bit_cast(unsigned, raw.w)}; }
+        else split4(v, hi, lo);
         const int u = rd * 256 + ltid;
         char* d = vsm + buf * kVBuf + ((u >> 1) & 1) * kVPlane + (u >> 2) * 16 + (u & 1) * 8;
+        if (dbg & 128) { asm volatile("" :: "v"(hi.x), "v"(hi.y), "v"(lo.x), "v"(lo.y)); continue; }
         *(u2*)d = hi;
         *(u2*)(d + 2 * kVPlane) = lo;
       }
     };
+#endif
+    if (dbg & 512) __builtin_amdgcn_s_setprio(3);
     // kLS register stages: chunk c+1 is stored while chunk c is multiplied, its loads were issued kLS - 1 iterations earlier
     // (UWM_V2_LS = 2: two chunks of latency budget; 3: three)
     constexpr int kLS = UWM_V2_LS;
@@ -643,7 +717,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
     // sides) through MMA wave k & 3.  Issued at the START of chunk cc - 1: the MMA waves have no other vector-memory traffic, so the
     // pieces have a whole chunk of MFMAs to land and the vmcnt(0) of the chunk's closing __syncthreads() finds them done
     auto a_dma = [&](int cc) {
-      if (!kALds || (dbg & 2)) return;
+      if (!kALds || (dbg & 2) || (dbg & 64)) return;
       char* const dst = asm_ + (cc & 1) * kABuf;
 #pragma unroll
       for (int i = 0; i < (kAPieces + 3) / 4; ++i) {
