@@ -493,6 +493,9 @@ typedef const __attribute__((address_space(1))) void v2_gbl_void;
 #ifndef UWM_V2_W128
 #define UWM_V2_W128 1         // 8-wave kernel: loader units of 8 channels, 16-byte LDS stores (0: 4 channels, 8-byte stores)
 #endif
+#ifndef UWM_V2_PD
+#define UWM_V2_PD 1           // 8-wave kernel, filters through LDS: fragment prefetch distance of the MMA waves (taps)
+#endif
 #ifndef UWM_V2_LS
 #define UWM_V2_LS 2           // 8-wave kernel: register stages of the loader waves (chunks of load latency budget)
 #endif
@@ -764,8 +767,9 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
           for (int j = 0; j < NCF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[j], xh[i], acc[i][j], 0, 0, 0);
       }
     };
+    constexpr int kPD = UWM_V2_PD;                       // LDS prefetch distance of the MMA waves in taps (1 or 2)
     h8 w_hi[kSD][NCF], w_lo[kSD][NCF];
-    h8 x_h[2][2], x_l[2][2];
+    h8 x_h[3][2], x_l[3][2];
     if (!kALds) {
 #pragma unroll
       for (int d = 0; d < kSD - 1; ++d) w_load(d < nsteps ? d : nsteps - 1, w_hi[d], w_lo[d]);
@@ -778,11 +782,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
       if (kALds && c + 1 < nchunk) a_dma(c + 1);
       x_load(0, pc, x_h[0], x_l[0]);
       if (kALds) w_lds(c, 0, w_hi[0], w_lo[0]);
+      if (kALds && kPD == 2) { x_load(1, pc, x_h[1], x_l[1]); w_lds(c, 1, w_hi[1], w_lo[1]); }
 #pragma unroll
       for (int ks = 0; ks < 9; ++ks) {
         const int t = c * 9 + ks;
         const int xsn = ks & 1;
-        if (kALds) {                                       // both operands from LDS, one tap ahead
+        if (kALds && kPD == 2) {                           // both operands from LDS, TWO taps ahead (three register sets: 9 taps = 3 x 3)
+          const int cur = ks % 3, nx2 = (ks + 2) % 3;
+          if (ks < 7) { w_lds(c, ks + 2, w_hi[nx2], w_lo[nx2]); x_load(ks + 2, pc, x_h[nx2], x_l[nx2]); }
+          __builtin_amdgcn_sched_barrier(0);
+          mma(w_hi[cur], w_lo[cur], x_h[cur], x_l[cur]);
+        } else if (kALds) {                                // both operands from LDS, one tap ahead
           if (ks < 8) { w_lds(c, ks + 1, w_hi[xsn ^ 1], w_lo[xsn ^ 1]); x_load(ks + 1, pc, x_h[xsn ^ 1], x_l[xsn ^ 1]); }
           __builtin_amdgcn_sched_barrier(0);
           mma(w_hi[xsn], w_lo[xsn], x_h[xsn], x_l[xsn]);
