@@ -51,7 +51,7 @@ constexpr int kVPlane = kVPP * 16;                     // bytes per plane: [pixe
 constexpr int kVBuf = 4 * kVPlane;                     // [octet 0 hi][octet 1 hi][octet 0 lo][octet 1 lo] = 21 760 bytes
 constexpr int kVUnits = kVPP * 4;                      // 16-byte fp32 units of a chunk (pixel x channel quad): 1360
 constexpr int kVRounds = (kVUnits + 255) / 256;        // 6 (the last one: 80 units)
-constexpr int kVQLd = 68;                              // epilogue block: floats per pixel (64 + 4 pad)
+template <int NCF> struct VQ { static constexpr int kLd = 32 * NCF + 4; };      // epilogue block: floats per pixel (32 or 64 + 4 pad)
 
 // ---------------------------------------------------------------- filter bank (layout 1 of f16x3_weights_multi: WinoJob::pad_ == 1)
 // bank = [C/16 chunks][9 taps][nF 32-row fragments][2 planes][64 lanes][8 halfs]; lane l of a fragment holds row (l & 31),
@@ -132,7 +132,7 @@ __device__ __forceinline__ void split4(f4 x, u2& hi, u2& lo) {
 }
 
 // ---------------------------------------------------------------- epilogue (shared by the 4-wave and the 8-wave kernel)
-// R = one MMA wave's block [64 pixels = 2 image rows x 32][kVQLd floats] (raw accumulators); this wave finishes pixels
+// R = one MMA wave's block [64 pixels = 2 image rows x 32][32 NCF + 4 floats] (raw accumulators); this wave finishes pixels
 // [p0, p0 + np) of it with lanes along the channels (whole 128- / 256-byte pixel rows per store): row un-scale, bias, residual
 // addend, ReLU mask, BatchNorm statistics / fused BatchNorm-backward sums — conv_f16x3_kernel's contract.  hb = image row of the
 // block's first row.  The concat-split form (ConvArgs::out_up, NCF = 2 only) sums 2 x 2 pixel blocks and needs np = 64.
@@ -156,8 +156,8 @@ __device__ __forceinline__ void v2_epilogue(const ConvArgs& a, const float* R, i
 #pragma unroll
         for (int r = 0; r < 16 / kSub; ++r) {
           const int bx = r * kSub + sub;                   // block column 0..15
-          const float* q = R + (2 * bx) * kVQLd + cq * 4;
-          f4 v = (*(const f4*)q + *(const f4*)(q + kVQLd) + *(const f4*)(q + 32 * kVQLd) + *(const f4*)(q + 33 * kVQLd)) * rs;
+          const float* q = R + (2 * bx) * VQ<NCF>::kLd + cq * 4;
+          f4 v = (*(const f4*)q + *(const f4*)(q + VQ<NCF>::kLd) + *(const f4*)(q + 32 * VQ<NCF>::kLd) + *(const f4*)(q + 33 * VQ<NCF>::kLd)) * rs;
           const size_t o2 = (((size_t)n * (a.Ho >> 1) + (hb >> 1)) * (a.Wo >> 1) + ((w0 >> 1) + bx)) * a.up_c0 + co;
           if (a.up_mask) {
             f4 mk = *(const f4*)(a.up_mask + o2);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void v2_epilogue(const ConvArgs& a, const float* R, i
         for (int r = 0; r < 64 / kSub; ++r) {
           const int p = r * kSub + sub;
           const int ho = hb + (p >> 5), wo = w0 + (p & 31);
-          *(f4*)(a.out + (((size_t)n * a.Ho + ho) * a.Wo + wo) * c1n + (co - a.up_c0)) = *(const f4*)(R + p * kVQLd + cq * 4) * rs;
+          *(f4*)(a.out + (((size_t)n * a.Ho + ho) * a.Wo + wo) * c1n + (co - a.up_c0)) = *(const f4*)(R + p * VQ<NCF>::kLd + cq * 4) * rs;
         }
       }
     }
@@ -193,7 +193,7 @@ __device__ __forceinline__ void v2_epilogue(const ConvArgs& a, const float* R, i
     const int ho = hb + (p >> 5), wo = w0 + (p & 31);
     if (cok) {
       const size_t o = (((size_t)n * a.Ho + ho) * a.Wo + wo) * a.Cout + co;
-      f4 v = *(const f4*)(R + p * kVQLd + cq * 4) * rs + bia;
+      f4 v = *(const f4*)(R + p * VQ<NCF>::kLd + cq * 4) * rs + bia;
       if (a.addend) v += *(const f4*)(a.addend + o);
       f4 yr = {0.f, 0.f, 0.f, 0.f};
       if (a.mask) {
@@ -463,14 +463,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3v2_kernel(const ConvArgs a) 
   // ---------------- epilogue: D[row = channel][col = pixel]; lane (pixel pcol, half kh) holds channels 8q + 4kh .. +3 (q = 0..3) of
   // each 32-channel fragment.  Every wave passes its 64 px x kCo block through LDS ([pixel][68] floats, its own region; the patch
   // buffers are dead) and reads it back with lanes along the channels: whole 128- / 256-byte pixel rows per store instruction
-  float* const R = (float*)vsm + wave * 64 * kVQLd;
+  float* const R = (float*)vsm + wave * 64 * VQ<NCF>::kLd;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NCF; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *(f4*)(R + (i * 32 + pcol) * kVQLd + j * 32 + q * 8 + kh * 4) = (f4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        *(f4*)(R + (i * 32 + pcol) * VQ<NCF>::kLd + j * 32 + q * 8 + kh * 4) = (f4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
   __syncthreads();
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
   v2_epilogue<NCF>(a, R, 0, 64, n, h0 + 2 * wave, w0, n0, lane, 1.f / xs, ps_, pq_);
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
 
   constexpr int kTrip = (kSD == 4 || kSD == 2) ? (kSD == 4 ? 4 : 2) : (kSD == 3 ? 1 : 0);      // chunks per loop trip: (9 * kTrip) % kSD == 0
   static_assert(kTrip > 0 && (9 * kTrip) % kSD == 0, "UWM_V2_SD must be 2, 3 or 4");
-  extern __shared__ __attribute__((aligned(16))) char vsm[];      // [2][kVBuf] patch buffers; the epilogue's [4][64][kVQLd] floats
+  extern __shared__ __attribute__((aligned(16))) char vsm[];      // [2][kVBuf] patch buffers; the epilogue's [4][64][VQ<NCF>::kLd] floats
   char* const asm_ = vsm + 2 * kVBuf;                  // [2][kABuf] behind the patch buffers (kALds)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -826,17 +826,17 @@ __global__ __launch_bounds__(512, 1) void conv_f16x3v2s_kernel(const ConvArgs a)
   // region; waves w and w + 4 finish its first and its second image row (the concat-split form sums 2 x 2 blocks across the two
   // rows: the MMA waves do it alone)
   if (is_mma) {
-    float* const Rw = (float*)vsm + mw * 64 * kVQLd;
+    float* const Rw = (float*)vsm + mw * 64 * VQ<NCF>::kLd;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NCF; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *(f4*)(Rw + (i * 32 + pcol) * kVQLd + j * 32 + q * 8 + kh * 4) = (f4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          *(f4*)(Rw + (i * 32 + pcol) * VQ<NCF>::kLd + j * 32 + q * 8 + kh * 4) = (f4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
   }
   __syncthreads();
-  const float* const R = (const float*)vsm + mw * 64 * kVQLd;
+  const float* const R = (const float*)vsm + mw * 64 * VQ<NCF>::kLd;
   f4 ps_ = {0.f, 0.f, 0.f, 0.f}, pq_ = ps_;
   if (NCF == 2 && a.out_up != nullptr) { if (is_mma) v2_epilogue<NCF>(a, R, 0, 64, n, h0 + 2 * mw, w0, n0, lane, 1.f / xs, ps_, pq_); }
   else v2_epilogue<NCF>(a, R, (wave >> 2) * 32, 32, n, h0 + 2 * mw, w0, n0, lane, 1.f / xs, ps_, pq_);
@@ -872,8 +872,7 @@ hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant) {
   if (a.out_up && (a.addend || a.mask || a.bias || a.bnb_y || (a.ssum && !a.bnb_mean) || (a.up_c0 < a.Cout && !a.out))) return hipErrorInvalidValue;
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !(a.out_up ? a.up_mask : (a.bnb_y ? a.bnb_y : a.mask)) || a.up_accum)) return hipErrorInvalidValue;
   const int tiles = a.N * (a.Ho / kVH) * (a.Wo / kVW);
-  const size_t main_lds = (size_t)2 * kVBuf + (size_t)kVRounds * 256 * sizeof(int), q_lds = (size_t)4 * 64 * kVQLd * sizeof(float);
-  const size_t lds = main_lds > q_lds ? main_lds : q_lds;
+  const size_t main_lds = (size_t)2 * kVBuf + (size_t)kVRounds * 256 * sizeof(int);
   // which kernel (kernel-alone timings at 16 x 512^2, profiles/r04_*): 32-channel tiles -> the 8-wave kernel (128 -> 32 at 256^2: 260 us
   // against 275 on the 4-wave kernel and 394 on conv_f16x3.hip's); 64-channel tiles -> the 4-wave kernel while the launch gives every
   // CU two workgroups (they cover each other's prologue and epilogue: 64 -> 64 at 128^2 71 vs 85 us), the 8-wave kernel below that
@@ -887,6 +886,10 @@ hipError_t launch_conv_f16x3v2(const ConvArgs& a, hipStream_t st, int variant) {
   if ((v == 4 || v == 6) && (a.Cout & 63)) return hipErrorInvalidValue;
   if ((v == 5 || v == 7) && a.out_up) return hipErrorInvalidValue;
   const int ncf = (v == 4 || v == 6) ? 2 : 1;
+  // epilogue blocks: 4 waves x 64 pixels x (32 ncf + 4) floats — 36.9 KB at 32-channel tiles, so the 4-wave kernel's 49.6 KB of
+  // staging LDS (and its 168 VGPRs) admit THREE workgroups per CU there
+  const size_t q_lds = (size_t)4 * 64 * (32 * ncf + 4) * sizeof(float);
+  const size_t lds = main_lds > q_lds ? main_lds : q_lds;
   const unsigned grid = (unsigned)(tiles * (a.Cout / (32 * ncf)));
   const int np = (a.nprod >= 1 && a.nprod <= 3) ? a.nprod : 3;
   if (v == 6 || v == 7) {
