@@ -877,6 +877,63 @@ def test_igemm_f16x3_stride2_layers(cuda, shape):
     assert derr["f16x3"] < 4 * derr["f32"] + 1e-7 and derr["f16x3"] < 2e-5, derr
 
 
+@pytest.mark.parametrize("n,hs,ws,lazy", [(2, 16, 32, True), (1, 8, 16, False), (3, 24, 48, True)])
+def test_conv_up2_f16x3_forward_and_dgrad(cuda, n, hs, ws, lazy):
+    """decoder block 4 conv1 (sub-pixel form) on conv_up2_f16.hip — the fp16x3 split products on v_mfma_f32_16x16x32_f16 the model
+    takes in the fp16x3 precision modes (ConvArgs::ig16): forward output + BatchNorm statistics and the dgrad with the fused concat
+    split (2x2-pooled, ReLU-masked gradient of the low-resolution producer; dY as tiny as a real Dice gradient, scaled through
+    max|dY|) against fp64, within 4x the exact-fp32 sub-pixel kernel's own error."""
+    L = lib()
+    g = torch.Generator().manual_seed(41 + hs)
+    a = torch.randn(n, 32, hs, ws, generator=g) * 3.0
+    sc = torch.rand(32, generator=g) + 0.5; sh = torch.randn(32, generator=g) * 0.3
+    sc[::7] *= -1
+    wt = torch.randn(16, 32, 3, 3, generator=g) * 0.08
+    act = torch.relu(a * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if lazy else a
+    y = F.conv2d(F.interpolate(act.double(), scale_factor=2, mode="nearest"), wt.double(), None, padding=1)
+    ad = nhwc(a.to(cuda)); wp, kpad = pack_w(wt.to(cuda))
+    t = [sc.to(cuda), sh.to(cuda)]
+    s0 = src(ad, t[0], t[1], relu=1, up=1) if lazy else src(ad, up=1)
+    errs = {}
+    for name, on in (("f32", 0), ("f16x3", 1)):
+        L.lib().uwm_op_set_igemm_f16x3(on)
+        try:
+            out = torch.full((n, 2 * hs, 2 * ws, 16), float("nan"), device=cuda)
+            stats = torch.zeros(32, dtype=torch.float64, device=cuda)
+            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), 16, kpad, 3, 3, 1, 1, n, 16, None, P(out), P(stats), -1, stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib().uwm_op_set_igemm_f16x3(0)
+        got = nchw(out.cpu(), 16).double()
+        errs[name] = float((got - y).abs().max() / y.abs().max())
+        assert torch.allclose(stats[:16].cpu(), y.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(stats[16:].cpu(), (y * y).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert errs["f16x3"] < 4 * errs["f32"] + 1e-7 and errs["f16x3"] < 1e-5, errs
+    # ---- dgrad with the fused concat split
+    prev = (torch.randn(n, 32, hs, ws, generator=g)).double().requires_grad_()
+    ap = torch.relu(prev * sc.double()[:, None, None] + sh.double()[:, None, None])
+    ap.retain_grad()
+    yy = F.conv2d(F.interpolate(ap, scale_factor=2, mode="nearest"), wt.double(), None, 1, 1)
+    dy = torch.randn(yy.shape, generator=g) * 1e-6
+    yy.backward(dy.double())
+    ref_prev = (ap.grad * (ap.detach() > 0)).permute(0, 2, 3, 1)
+    kpadd = rup(9 * 16, 32)
+    wd = torch.empty(32, kpadd, device=cuda)
+    L.check(L.lib().uwm_op_pack_dgrad(P(wp), 16, kpad, 9, 32, P(wd), kpadd, 16, stream()))
+    dyd = nhwc(dy).to(cuda); pm = nhwc(prev.detach().float()).to(cuda)
+    derr = {}
+    for name, on in (("f32", 0), ("f16x3", 1)):
+        L.lib().uwm_op_set_igemm_f16x3(on)
+        try:
+            gp = torch.full((n, hs, ws, 32), float("nan"), device=cuda)
+            L.check(L.lib().uwm_op_dgrad_upsplit(P(dyd), n, 2 * hs, 2 * ws, 16, P(wd), 32, 0, kpadd, P(gp), P(pm), P(t[0]), P(t[1]), None, stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib().uwm_op_set_igemm_f16x3(0)
+        derr[name] = float((gp.cpu().double() - ref_prev).abs().max() / ref_prev.abs().max())
+    assert derr["f16x3"] < 4 * derr["f32"] + 1e-7 and derr["f16x3"] < 1e-5, derr
+
+
 def test_conv_f16x3_upsample_concat(cuda):
     """decoder conv1 on the fp16x3 kernel: cat(nearest_x2(d), skip), both sources lazy, concat boundary on a 16-channel chunk."""
     L = lib()

@@ -195,6 +195,7 @@ bool conv_up2_applicable(const ConvArgs& a) {
 
 hipError_t launch_conv_up2(const ConvArgs& a, hipStream_t st) {
   if (!conv_up2_applicable(a)) return hipErrorInvalidValue;
+  if (a.ig16) return launch_conv_up2_f16(a, st);
   const size_t lds = (size_t)(2 * kUPP * kUC + 16 * kUWLd) * sizeof(float);
   const int ntiles = a.N * (a.s0.H / kUH) * (a.s0.W / kUW);
   const int nwg = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();
@@ -377,6 +378,7 @@ bool conv_up2_dgrad_applicable(const ConvArgs& a) {
 
 hipError_t launch_conv_up2_dgrad(const ConvArgs& a, hipStream_t st) {
   if (!conv_up2_dgrad_applicable(a)) return hipErrorInvalidValue;
+  if (a.ig16) return launch_conv_up2_dgrad_f16(a, st);
   if (a.bnb_mean && (!a.ssum || !a.ssq || !a.bnb_rstd || !a.up_mask || a.up_accum)) return hipErrorInvalidValue;
   const size_t lds = (size_t)(32 * kDWLd + 2 * kDBuf) * sizeof(float);
   const int ntiles = a.N * ((a.Ho >> 1) / kDH) * ((a.Wo >> 1) / kDW);

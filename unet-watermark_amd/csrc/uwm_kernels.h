@@ -92,7 +92,7 @@ struct ConvArgs {            // implicit-GEMM conv: forward conv AND dgrad (tran
   int wu_rinv_off;           // prec 2: float offset of the bank's 1 / row-scale array from wu
   const float* xmax;         // prec 2: 32 device floats whose maximum is max|input| (a dgrad's dY, written by bn_bwd_apply), or nullptr: the input is staged times the power of two that puts that maximum in [2^13, 2^14), undone in the epilogue
   int route_n;               // > 0: choose the kernel VARIANT as if the batch were route_n images (uwm_set_routing_batch: a small parity sample on the kernels the full batch takes); 0: N
-  int ig16;                  // implicit-GEMM launches (conv_igemm.hip: stride-2 3x3, 1x1 stride 2, their dgrads): 1 = fp16x3 split products on v_mfma_f32_16x16x32_f16 (operands split while staging, weights times 2^12, a dgrad's dY by xmax); 0 = exact fp32
+  int ig16;                  // implicit-GEMM launches (conv_igemm.hip: stride-2 3x3, 1x1 stride 2, their dgrads) and the sub-pixel decoder conv (conv_up2_f16.hip): 1 = fp16x3 split products on v_mfma_f32_16x16x32_f16 (operands split while staging, weights times 2^12, a dgrad's dY by xmax); 0 = exact fp32
   int nprod;                 // prec 2: split products per tile — 0 / 3: hi*hi' + hi*lo' + lo*hi' (fp32-class); 2: the pixel operand (a dgrad's dY) as ONE fp16 (hi*hi' + lo_w*hi'); 1: hi*hi' only (plain fp16 products, the reference's autocast arithmetic)
   int wu_layout;             // prec 2: layout of the fp16x3 bank behind wu — 0: conv_f16x3.hip (tap pairs, 16-row fragments), 1: conv_f16x3v2.hip (taps, 32-row fragments); set by whoever packed the bank (f16x3v2_shape)
 };
@@ -216,6 +216,9 @@ bool conv_up2_applicable(const ConvArgs& a);              // 3x3 over a nearest-
 hipError_t launch_conv_up2(const ConvArgs& a, hipStream_t st);
 bool conv_up2_dgrad_applicable(const ConvArgs& a);        // its dgrad wrt the low-resolution input, concat-split epilogue contract (ConvArgs::out_up)
 hipError_t launch_conv_up2_dgrad(const ConvArgs& a, hipStream_t st);
+// conv_up2_f16.hip: the same two launches on v_mfma_f32_16x16x32_f16 with fp16x3 split products (taken when ConvArgs::ig16 is set)
+hipError_t launch_conv_up2_f16(const ConvArgs& a, hipStream_t st);
+hipError_t launch_conv_up2_dgrad_f16(const ConvArgs& a, hipStream_t st);
 bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);
