@@ -469,6 +469,37 @@ def test_wgrad_stem_compact_columns(cuda, n, h, w):
     assert (full[..., 3] == 0).all() and (outs[0][:, 196:] == 0).all()
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 128, 192), (3, 32, 64)])
+def test_wgrad_stem_f16x3(cuda, n, h, w):
+    """wgrad_stem.hip's fp16x3 kernel (force 6: WgradArgs::prec == 2 — what the model takes for encoder.conv1 in the f16x3_all modes):
+    split products on v_mfma_f32_16x16x32_f16, both operands through transposing LDS reads, columns in dW's own tap*4 + c layout.
+    dY as tiny as a real Dice gradient (scaled through max|dY|); against fp64 autograd within 4x the exact-fp32 kernel's own error,
+    bit-identical between two launches, pad channel / pad K of dW left at zero."""
+    L = lib()
+    g = torch.Generator().manual_seed(61 + h)
+    x = torch.randn(n, 3, h, w, generator=g) * 1.5
+    wt = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).double().requires_grad_()
+    y = F.conv2d(x.double(), wt, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g) * 1e-6
+    y.backward(dy.double())
+    xd, dyd = nhwc(x).to(cuda), nhwc(dy).to(cuda)
+    kpad = rup(49 * 4, 32)
+    s0 = src(xd)
+    outs = {}
+    for name, force in (("f32", 0), ("f16x3", 6), ("again", 6)):
+        dw = torch.zeros(64, kpad, device=cuda)
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h // 2, w // 2, 64, 64, kpad, 7, 7, 2, 3, P(dw), force, stream()))
+        torch.cuda.synchronize()
+        outs[name] = dw.cpu()
+    assert torch.equal(outs["f16x3"], outs["again"])
+    ref = wt.grad
+    err = {k: float((unpack_w(outs[k], 64, 3, 7, 7).double() - ref).abs().max() / ref.abs().max()) for k in ("f32", "f16x3")}
+    assert err["f16x3"] < 4 * err["f32"] + 1e-7 and err["f16x3"] < 1e-5, err
+    assert not torch.equal(outs["f16x3"], outs["f32"])          # (the fp16x3 kernel did run)
+    full = outs["f16x3"][:, :196].reshape(64, 49, 4)
+    assert (full[..., 3] == 0).all() and (outs["f16x3"][:, 196:] == 0).all()
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 128, 16, 16), (1, 256, 64, 32, 32), (4, 96, 40, 16, 16), (1, 160, 192, 32, 32), (2, 32, 32, 16, 8),
                                             (2, 56, 336, 16, 16), (1, 144, 32, 32, 32), (4, 24, 144, 16, 16)])      # Cin % 32 != 0: dW pad columns stay zero
 @pytest.mark.parametrize("lazy", [False, True])
