@@ -411,6 +411,48 @@ def test_wgrad_c16_and_head(cuda, cout, n, h, w):
     assert (runs[0][:, 9 * cin:] == 0).all()
 
 
+@pytest.mark.parametrize("n,h,w", [(4, 128, 128), (1, 8, 32), (2, 24, 96)])
+def test_wgrad_c16_f16x3(cuda, n, h, w):
+    """wgrad_c16.hip's fp16x3 kernel (force 6: WgradArgs::prec == 2 — decoder block 4 conv2 in the f16x3_all modes): split products
+    on v_mfma_f32_16x16x32_f16, both operands through transposing LDS reads, persistent double-buffered stages.  Lazy BatchNorm +
+    ReLU input (negative scales included), dY ~ 1e-6 (scaled through max|dY|); against fp64 autograd within 4x the exact-fp32
+    kernel's own error, bit-identical between two launches, dW accumulated (+=), padded K columns left at zero."""
+    L = lib()
+    g = torch.Generator().manual_seed(71 + h)
+    cin = cout = 16
+    xr = torch.randn(n, cin, h, w, generator=g) * 2.0
+    sc = torch.rand(cin, generator=g) + 0.5; sc[::5] *= -1
+    sh = torch.randn(cin, generator=g) * 0.3
+    x = torch.relu(xr * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).double().requires_grad_()
+    y = F.conv2d(x, wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g) * 1e-6
+    y.backward(dy.double())
+    kpad = rup(9 * cin, 32)
+    xd, dyd = nhwc(xr).to(cuda), nhwc(dy).to(cuda)
+    scd, shd = sc.to(cuda), sh.to(cuda)
+    s0 = src(xd, scd, shd, relu=1)
+    outs = {}
+    for name, force in (("f32", 0), ("f16x3", 6), ("again", 6)):
+        dw = torch.full((cout, kpad), 0.25, device=cuda); dw[:, 9 * cin:] = 0
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h, w, cout, cout, kpad, 3, 3, 1, 1, P(dw), force, stream()))
+        torch.cuda.synchronize()
+        outs[name] = dw.cpu()
+    assert torch.equal(outs["f16x3"], outs["again"])
+    assert not torch.equal(outs["f16x3"], outs["f32"])          # (the fp16x3 kernel did run)
+    ref = wt.grad
+    err = {k: float(((unpack_w(outs[k], cout, cin, 3, 3).double() - 0.25) - ref).abs().max() / ref.abs().max()) for k in ("f32", "f16x3")}
+    # (dW = 0.25 + a gradient of ~1e-5: both kernels sit at the fp32 rounding of that sum)
+    assert err["f16x3"] < 4 * err["f32"] + 1e-6, err
+    assert (outs["f16x3"][:, 9 * cin:] == 0).all()
+    # the same without the 0.25 offset: the gradient's own digits
+    dw = torch.zeros(cout, kpad, device=cuda)
+    L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, h, w, cout, cout, kpad, 3, 3, 1, 1, P(dw), 6, stream()))
+    torch.cuda.synchronize()
+    e0 = float((unpack_w(dw.cpu(), cout, cin, 3, 3).double() - ref).abs().max() / ref.abs().max())
+    assert e0 < 1e-5, e0
+
+
 @pytest.mark.parametrize("c0,c1,cout", [(32, 16, 16), (64, 32, 32), (32, 32, 64),
                                         (64, 48, 32), (32, 24, 64), (64, 56, 128)])      # channel tails of the EfficientNet decoder concats (Ctot % 32 != 0)
 def test_wgrad_lazy_upsample_concat(cuda, c0, c1, cout):
@@ -568,6 +610,39 @@ def test_wgrad_up2_subpixel(cuda, n, hs, ws):
     dw2 = torch.zeros(16, kpad, device=cuda)
     L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, 2 * hs, 2 * ws, 16, 16, kpad, 3, 3, 1, 1, P(dw2), 1, stream()))
     assert (dw2.cpu() - outs[0]).abs().max() < 3e-5 * max(1.0, float(wt.grad.abs().max()))
+
+
+@pytest.mark.parametrize("n,hs,ws", [(2, 16, 32), (1, 2, 32), (3, 8, 64)])
+def test_wgrad_up2_f16x3(cuda, n, hs, ws):
+    """decoder block 4 conv1 weight gradient on conv_up2_f16.hip's fp16x3 kernel (force 6: WgradArgs::prec == 2): the sixteen class
+    products with the low-resolution pixels as the MFMA k dimension, transposing LDS reads, the fp32 kernel's partial layout and
+    reduce.  Lazy input with negative scales, dY ~ 1e-6; against fp64 autograd within 4x the exact-fp32 sub-pixel kernel's own error,
+    bit-identical between two launches."""
+    L = lib()
+    g = torch.Generator().manual_seed(33 + hs)
+    d = torch.randn(n, 32, hs, ws, generator=g) * 2.0
+    sc0, sh0 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    sc0[::6] *= -1
+    a0 = torch.relu(d * sc0[:, None, None] + sh0[:, None, None]).double()
+    wt = (torch.randn(16, 32, 3, 3, generator=g) * 0.05).double().requires_grad_()
+    y = F.conv2d(F.interpolate(a0, scale_factor=2, mode="nearest"), wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g) * 1e-6
+    y.backward(dy.double())
+    dd, dyd = nhwc(d).to(cuda), nhwc(dy).to(cuda)
+    kpad = rup(9 * 32, 32)
+    t = [sc0.to(cuda), sh0.to(cuda)]
+    s0 = src(dd, t[0], t[1], relu=1, up=1)
+    outs = {}
+    for name, force in (("f32", 0), ("f16x3", 6), ("again", 6)):
+        dw = torch.zeros(16, kpad, device=cuda)
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, 2 * hs, 2 * ws, 16, 16, kpad, 3, 3, 1, 1, P(dw), force, stream()))
+        torch.cuda.synchronize()
+        outs[name] = dw.cpu()
+    assert torch.equal(outs["f16x3"], outs["again"])
+    assert not torch.equal(outs["f16x3"], outs["f32"])          # (the fp16x3 kernel did run)
+    ref = wt.grad
+    err = {k: float((unpack_w(outs[k], 16, 32, 3, 3).double() - ref).abs().max() / ref.abs().max()) for k in ("f32", "f16x3")}
+    assert err["f16x3"] < 4 * err["f32"] + 1e-7 and err["f16x3"] < 1e-5, err
 
 
 def test_maxpool_ties_and_lazy_input(cuda):

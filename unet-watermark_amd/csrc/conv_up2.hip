@@ -589,11 +589,18 @@ bool wgrad_up2_applicable(const WgradArgs& a) {
 hipError_t launch_wgrad_up2(const WgradArgs& a0, hipStream_t st) {
   if (!wgrad_up2_applicable(a0)) return hipErrorInvalidValue;
   WgradArgs a = a0;
+  const bool f16 = a.prec == 2 && a.xmax && wgrad_up2_f16_shape(a);      // fp16x3 precision modes: conv_up2_f16.hip's kernel, same partial layout
   const int ntiles = a.N * (a.s0.H / kGH) * (a.s0.W / kGW);
-  const int nwg = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();
+  const int nwg = f16 ? wgrad_up2_f16_parts(a) : (ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count());
   const size_t need = (size_t)nwg * kGPart;
   if (!a.part || a.part_floats < need) { a.part = wgrad_op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); }     // single-operator entry points
   if (!a.part || a.part_floats < need) return hipErrorOutOfMemory;
+  if (f16) {
+    hipError_t e = launch_wgrad_up2_f16(a, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_up2_reduce_kernel, dim3(9 * 2 * 64 / 8), dim3(256), 0, st, (const float*)a.part, nwg, a.dw, a.wrows, a.Kpad);
+    return hipGetLastError();
+  }
   size_t lds = (size_t)2 * kGBuf * sizeof(float);
   if (lds < 64 * 1024) lds = 64 * 1024;                  // the cross-wave sum needs [2][32][64] f4
   static DevOnce lds_attr;

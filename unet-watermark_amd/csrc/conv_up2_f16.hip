@@ -407,4 +407,184 @@ hipError_t launch_conv_up2_dgrad_f16(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------- wgrad
+// wgrad_up2_kernel's sixteen class products P[a][dpy][b][dpx][co][c] = sum dY[2i+a][2j+b][co] * X~[i-1+a+dpy][j-1+b+dpx][c]
+// (conv_up2.hip) with the pixels as the k dimension of v_mfma_f32_16x16x32_f16: a k-step = the 32 low-resolution pixels of a
+// tile row, both operands through the transposing LDS load ds_read_b64_tr_b16 out of pixel-major images (dY [4 rows][64 px][hi 16
+// co | lo], X~ [4][34][hi 32 ch | lo]; the stride-2 walk over dY and the neighbourhood shifts are lane addresses).  Tile = 2 x 32
+// low-resolution pixels; wave = (tile row, 16-channel block cb): 16 accumulators, 48 MFMAs per tile.  Persistent, stages
+// double-buffered.  The workgroup partial has wgrad_up2_kernel's layout: wgrad_up2_reduce_kernel folds both.
+typedef __fp16 u_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) u_fp16x4 u_lds_fp16x4;
+__device__ __forceinline__ h8 u_tr_pair(const char* base, int o0, int o1) {
+  const u_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((u_lds_fp16x4*)(uintptr_t)(base + o0));
+  const u_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((u_lds_fp16x4*)(uintptr_t)(base + o1));
+  typedef __fp16 fp16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+  const fp16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(h8, v);
+}
+namespace {
+constexpr int kWH = 2, kWW = 32;                                   // low-resolution pixels per tile
+constexpr int kWPW = kWW + 2, kWPix = (kWH + 2) * kWPW;            // 4 x 34 = 136 patch pixels
+constexpr int kWX = kWPix * 128;                                   // bytes of the X~ image (17 408)
+constexpr int kWDy = 2 * kWH * 2 * kWW * 64;                       // bytes of the dY image: 4 rows x 64 px x 64 B (16 384)
+constexpr int kWBuf = kWX + kWDy;
+constexpr int kWPart = 16 * 2 * 64 * 4;                            // floats per workgroup partial (= conv_up2.hip's kGPart)
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void wgrad_up2_f16_kernel(const WgradArgs a, int ntiles) {
+  extern __shared__ __attribute__((aligned(256))) char smem_[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kr = wave >> 1, cb = wave & 1;
+  const int Hs = a.s0.H, Wsrc = a.s0.W;
+  const int tilesW = Wsrc / kWW, tilesH = Hs / kWH;
+  const float xs = dy_scale(a.xmax, lane);
+
+  // ---- staging: X~ 136 px x 8 quads = 1088 units (5 rounds), dY 256 px x 4 quads = 1024 units (4 rounds)
+  const int xunit = tid & 7, yunit = tid & 3;
+  const bool has = a.s0.scale != nullptr;
+  f4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (has) { sc = *(const f4*)(a.s0.scale + xunit * 4); sh = *(const f4*)(a.s0.shift + xunit * 4); }
+  const float vlo = (has && a.s0.relu) ? 0.f : -65504.f;
+  int xpy[5], xpx[5];
+#pragma unroll
+  for (int rd = 0; rd < 5; ++rd) {
+    const int pp = min((rd * 256 + tid) >> 3, kWPix - 1);
+    xpy[rd] = pp / kWPW; xpx[rd] = pp - xpy[rd] * kWPW;
+  }
+  const bool xlast = (4 * 256 + tid) < kWPix * 8;
+  f4 xv[5], yv[4]; unsigned xok = 0;
+  auto tile_origin = [&](int t, int& n, int& h0, int& w0) {
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; n = t / tilesH;
+    h0 = th * kWH; w0 = tw * kWW;
+  };
+  auto stage_load = [&](int t) {
+    int n, h0, w0; tile_origin(t, n, h0, w0);
+    xok = 0;
+#pragma unroll
+    for (int rd = 0; rd < 5; ++rd) {
+      const int hl = h0 - 1 + xpy[rd], wl = w0 - 1 + xpx[rd];
+      const bool ok = hl >= 0 && hl < Hs && wl >= 0 && wl < Wsrc;
+      const int hc = min(max(hl, 0), Hs - 1), wc = min(max(wl, 0), Wsrc - 1);
+      xv[rd] = *(const f4*)(a.s0.ptr + (((size_t)n * Hs + hc) * Wsrc + wc) * 32 + xunit * 4);
+      xok |= (ok ? 1u : 0u) << rd;
+    }
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const int px = (rd * 256 + tid) >> 2;                // dY pixel of the 4 x 64 tile
+      yv[rd] = *(const f4*)(a.dy + (((size_t)n * a.Ho + 2 * h0 + (px >> 6)) * a.Wo + 2 * w0 + (px & 63)) * 16 + yunit * 4);
+    }
+  };
+  auto stage_store = [&](int buf) {
+    char* const xb = smem_ + buf * kWBuf;
+    char* const yb = xb + kWX;
+#pragma unroll
+    for (int rd = 0; rd < 5; ++rd) {
+      f4 v = xv[rd];
+      if (has) v = v * sc + sh;
+      const bool ok = (xok >> rd) & 1u;
+      const float top = ok ? 65504.f : vlo;
+      v.x = __builtin_amdgcn_fmed3f(v.x, vlo, top); v.y = __builtin_amdgcn_fmed3f(v.y, vlo, top);
+      v.z = __builtin_amdgcn_fmed3f(v.z, vlo, top); v.w = __builtin_amdgcn_fmed3f(v.w, vlo, top);
+      if (vlo != 0.f && !ok) v = (f4){0.f, 0.f, 0.f, 0.f};
+      uwm_u2 hi, lo;
+      uwm_split4(v.x, v.y, v.z, v.w, hi, lo);
+      const int pp = (rd * 256 + tid) >> 3;
+      if (rd < 4 || xlast) { *(uwm_u2*)(xb + pp * 128 + xunit * 8) = hi; *(uwm_u2*)(xb + pp * 128 + 64 + xunit * 8) = lo; }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const f4 v = yv[rd] * xs;                           // (below 2^14 by construction: no clamp)
+      uwm_u2 hi, lo;
+      uwm_split4(v.x, v.y, v.z, v.w, hi, lo);
+      const int px = (rd * 256 + tid) >> 2;
+      *(uwm_u2*)(yb + px * 64 + yunit * 8) = hi; *(uwm_u2*)(yb + px * 64 + 32 + yunit * 8) = lo;
+    }
+  };
+  // ---- fragment addresses: lane = (k-group kg, row-in-group q, quad p): low-resolution column 8 kg + q (+4)
+  const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int yo = (2 * kr * 64 + 2 * (8 * kg + q)) * 64 + p * 8;                    // + (pa * 64 + pb) * 64; second read + 8 px = + 512 B; lo + 32
+  const int xo = (kr * kWPW + 8 * kg + q) * 128 + cb * 32 + p * 8;                 // + (py * kWPW + px) * 128; second read + 4 px = + 512 B; lo + 64
+
+  f4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  int t = blockIdx.x;
+  if (t < ntiles) { stage_load(t); stage_store(0); }
+  __syncthreads();
+  for (int it = 0; t < ntiles; ++it, t += gridDim.x) {
+    const int cur = it & 1;
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < ntiles;
+    if (more) stage_load(tn);
+    const char* const xb = smem_ + cur * kWBuf;
+    const char* const yb = xb + kWX;
+    h8 ah[2][2], al[2][2];
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        const char* const ya = yb + yo + (pa * 64 + pb) * 64;
+        ah[pa][pb] = u_tr_pair(ya, 0, 512); al[pa][pb] = u_tr_pair(ya, 32, 512 + 32);
+      }
+#pragma unroll
+    for (int py = 0; py < 3; ++py)
+#pragma unroll
+      for (int px = 0; px < 3; ++px) {
+        const char* const xa = xb + xo + (py * kWPW + px) * 128;
+        const h8 bh = u_tr_pair(xa, 0, 512), bl = u_tr_pair(xa, 64, 512 + 64);
+        // (py, px) = (pa + dy_, pb + dx_): the class products this neighbourhood pixel feeds
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int dy_ = py - pa, dx_ = px - pb;
+            if (dy_ >= 0 && dy_ < 2 && dx_ >= 0 && dx_ < 2) {
+              const int pi = ((pa * 2 + dy_) * 2 + pb) * 2 + dx_;
+              f4 c = acc[pi];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pa][pb], bl, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[pa][pb], bh, c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[pa][pb], bh, c, 0, 0, 0);
+              acc[pi] = c;
+            }
+          }
+      }
+    if (more) stage_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- the two tile rows of a channel block: waves 2, 3 -> LDS -> waves 0, 1, which store the workgroup partial [16][2 cb][64][4]
+  f4* const red = (f4*)smem_;                             // [2 cb][16][64] f4 = 32 KB
+  const float ixs = 1.f / xs;
+  if (kr == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[(cb * 16 + i) * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (kr == 0) {
+    f4* const out = (f4*)(a.part + (size_t)blockIdx.x * kWPart);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[(i * 2 + cb) * 64 + lane] = (acc[i] + red[(cb * 16 + i) * 64 + lane]) * ixs;
+  }
+}
+
+// the main launch (conv_up2.hip's launch_wgrad_up2 sizes the scratch and runs wgrad_up2_reduce_kernel behind it): returns the
+// number of workgroup partials
+bool wgrad_up2_f16_shape(const WgradArgs& a) { return (a.s0.H % kWH) == 0 && (a.s0.W % kWW) == 0; }
+int wgrad_up2_f16_parts(const WgradArgs& a) {
+  const int ntiles = a.N * (a.s0.H / kWH) * (a.s0.W / kWW);
+  return ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();
+}
+hipError_t launch_wgrad_up2_f16(const WgradArgs& a, hipStream_t st) {
+  const int ntiles = a.N * (a.s0.H / kWH) * (a.s0.W / kWW);
+  const int nwg = wgrad_up2_f16_parts(a);
+  const size_t lds = (size_t)2 * kWBuf;
+  static DevOnce lds_attr;
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_up2_f16_kernel, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(36, a.flops, a.bytes, wgrad_up2_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+  return hipGetLastError();
+}
+
 }  // namespace uwm

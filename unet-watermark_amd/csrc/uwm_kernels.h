@@ -219,6 +219,9 @@ hipError_t launch_conv_up2_dgrad(const ConvArgs& a, hipStream_t st);
 // conv_up2_f16.hip: the same two launches on v_mfma_f32_16x16x32_f16 with fp16x3 split products (taken when ConvArgs::ig16 is set)
 hipError_t launch_conv_up2_f16(const ConvArgs& a, hipStream_t st);
 hipError_t launch_conv_up2_dgrad_f16(const ConvArgs& a, hipStream_t st);
+bool wgrad_up2_f16_shape(const WgradArgs& a);             // its weight gradient: 2 x 32 low-resolution tiles
+int wgrad_up2_f16_parts(const WgradArgs& a);              // workgroup partials of that launch (wgrad_up2_kernel's layout)
+hipError_t launch_wgrad_up2_f16(const WgradArgs& a, hipStream_t st);
 bool conv_patch_applicable(const ConvArgs& a);
 bool conv_patch16_applicable(const ConvArgs& a);          // 16-channel inputs: whole K in LDS (conv_patch16.hip)
 hipError_t launch_conv_patch16(const ConvArgs& a, hipStream_t st);

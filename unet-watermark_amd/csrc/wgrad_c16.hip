@@ -189,6 +189,161 @@ __global__ __launch_bounds__(256, 3) void wgrad_head_kernel(const WgradArgs a, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fp16x3 form of wgrad_c16_kernel
+// (the fp16x3 precision modes: WgradArgs::prec == 2, dY scaled through WgradArgs::xmax).  The fp32 kernel is bound by its MFMAs
+// (9 of 32 cycles per 4 pixels: 123 of its 204 us); here one v_mfma_f32_16x16x32_f16 k-step = the 32 pixels of a tile row, three
+// split products per tap (27 MFMAs of 16 cycles per row), both operands through the transposing LDS load ds_read_b64_tr_b16 out of
+// pixel-major images [px][hi 16 ch | lo 16 ch] (64 B per pixel) — a tap shift is just another row address.  Persistent workgroups,
+// the stage (dY tile + x~ halo patch, split while staging) double-buffered: the next tile's global loads are in flight behind this
+// tile's MFMAs, one barrier per tile.
+typedef _Float16 c_h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 c_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) c_fp16x4 c_lds_fp16x4;
+__device__ __forceinline__ c_h8 c_tr_pair(const char* base, int o0, int o1) {
+  const c_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((c_lds_fp16x4*)(uintptr_t)(base + o0));
+  const c_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((c_lds_fp16x4*)(uintptr_t)(base + o1));
+  typedef __fp16 fp16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+  const fp16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(c_h8, v);
+}
+constexpr int kFDy = kRows * kCols * 64;                     // bytes of the dY image (16 KB)
+constexpr int kFX = kPR * kPC * 64;                          // bytes of the x~ image (21 760)
+constexpr int kFBuf = kFDy + kFX;
+
+__global__ __launch_bounds__(256, 2) void wgrad_c16_f16_kernel(const WgradArgs a, const C16Geo g) {
+  extern __shared__ __attribute__((aligned(256))) char fsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.Ho, W = a.Wo;
+  float xs = 1.f;
+  if (a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
+  // ---- staging geometry: thread = (pixel, channel quad); x~ 340 px x 4 = 1360 units (6 rounds), dY 256 px x 4 = 1024 units (4 rounds)
+  const int chu = tid & 3;
+  f4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  const bool has = a.s0.scale != nullptr;
+  if (has) { sc = *(const f4*)(a.s0.scale + chu * 4); sh = *(const f4*)(a.s0.shift + chu * 4); }
+  const float vlo = (has && a.s0.relu) ? 0.f : -65504.f;
+  int xpy[6], xpx[6];
+#pragma unroll
+  for (int rd = 0; rd < 6; ++rd) {
+    const int pp = min((rd * 256 + tid) >> 2, kPR * kPC - 1);
+    xpy[rd] = pp / kPC; xpx[rd] = pp - xpy[rd] * kPC;
+  }
+  const bool xlast = (5 * 256 + tid) < kPR * kPC * 4;
+  f4 xv[6], dv[4]; unsigned xok = 0;
+  auto tile_origin = [&](int t, int& n, int& h0, int& w0) {
+    const int tw = t % g.tilesW; t /= g.tilesW;
+    const int th = t % g.tilesH; n = t / g.tilesH;
+    h0 = th * kRows; w0 = tw * kCols;
+  };
+  auto stage_load = [&](int t) {
+    int n, h0, w0; tile_origin(t, n, h0, w0);
+    xok = 0;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      const int hh = h0 - 1 + xpy[rd], ww = w0 - 1 + xpx[rd];
+      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      const int hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
+      xv[rd] = *(const f4*)(a.s0.ptr + (((size_t)n * H + hc) * W + wc) * kC + chu * 4);
+      xok |= (ok ? 1u : 0u) << rd;
+    }
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const int px = (rd * 256 + tid) >> 2;
+      dv[rd] = *(const f4*)(a.dy + (((size_t)n * H + h0 + (px >> 5)) * W + w0 + (px & 31)) * kC + chu * 4);
+    }
+  };
+  auto stage_store = [&](int buf) {
+    char* const yb = fsm + buf * kFBuf;
+    char* const xb = yb + kFDy;
+#pragma unroll
+    for (int rd = 0; rd < 6; ++rd) {
+      f4 v = xv[rd];
+      if (has) v = v * sc + sh;
+      const bool ok = (xok >> rd) & 1u;
+      const float top = ok ? 65504.f : vlo;
+      v.x = __builtin_amdgcn_fmed3f(v.x, vlo, top); v.y = __builtin_amdgcn_fmed3f(v.y, vlo, top);
+      v.z = __builtin_amdgcn_fmed3f(v.z, vlo, top); v.w = __builtin_amdgcn_fmed3f(v.w, vlo, top);
+      if (vlo != 0.f && !ok) v = (f4){0.f, 0.f, 0.f, 0.f};
+      uwm_u2 hi, lo;
+      uwm_split4(v.x, v.y, v.z, v.w, hi, lo);
+      const int u = rd * 256 + tid;
+      if (rd < 5 || xlast) { *(uwm_u2*)(xb + (u >> 2) * 64 + chu * 8) = hi; *(uwm_u2*)(xb + (u >> 2) * 64 + 32 + chu * 8) = lo; }
+    }
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const f4 v = dv[rd] * xs;                           // (below 2^14 by construction: no clamp)
+      uwm_u2 hi, lo;
+      uwm_split4(v.x, v.y, v.z, v.w, hi, lo);
+      const int px = (rd * 256 + tid) >> 2;
+      *(uwm_u2*)(yb + px * 64 + chu * 8) = hi; *(uwm_u2*)(yb + px * 64 + 32 + chu * 8) = lo;
+    }
+  };
+  // ---- fragment addresses: lane = (k-group kg, row-in-group q, channel quad p): pixel 8 kg + q (+4) of the k-step's row
+  const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int fo = (8 * kg + q) * 64 + p * 8;
+
+  f4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  int t = blockIdx.x;
+  if (t < g.ntiles) { stage_load(t); stage_store(0); }
+  __syncthreads();
+  for (int it = 0; t < g.ntiles; ++it, t += gridDim.x) {
+    const int cur = it & 1;
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < g.ntiles;
+    if (more) stage_load(tn);
+    const char* const yb = fsm + cur * kFBuf;
+    const char* const xb = yb + kFDy;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = wave * 2 + rr;
+      const char* const ya = yb + row * kCols * 64 + fo;
+      const c_h8 ah = c_tr_pair(ya, 0, 256), al = c_tr_pair(ya, 32, 256 + 32);
+#pragma unroll
+      for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const char* const xa = xb + ((row + r3) * kPC + s3) * 64 + fo;
+          const c_h8 bh = c_tr_pair(xa, 0, 256), bl = c_tr_pair(xa, 32, 256 + 32);
+          f4 c = acc[r3 * 3 + s3];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+          acc[r3 * 3 + s3] = c;
+        }
+    }
+    if (more) stage_store(cur ^ 1);
+    __syncthreads();
+  }
+  // ---- the four waves' sums -> LDS -> one partial tile [16 co][Kpad] per workgroup (pad columns written as zeros)
+  float* const red = (float*)fsm;                           // [4][9][16 co][16 ci]
+  const int li = lane & 15, lq = lane >> 4;
+  const float ixs = 1.f / xs;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[((wave * 9 + t9) * 16 + lq * 4 + e) * 16 + li] = acc[t9][e] * ixs;
+  __syncthreads();
+  float* const dst = a.part + (size_t)blockIdx.x * a.wrows * a.Kpad;
+  const int co = tid >> 4, ci = tid & 15;
+  if (co < a.wrows) {
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const float s = (red[((0 * 9 + t9) * 16 + co) * 16 + ci] + red[((1 * 9 + t9) * 16 + co) * 16 + ci]) +
+                      (red[((2 * 9 + t9) * 16 + co) * 16 + ci] + red[((3 * 9 + t9) * 16 + co) * 16 + ci]);
+      dst[(size_t)co * a.Kpad + t9 * kC + ci] = s;
+    }
+    for (int k = 9 * kC + ci; k < a.Kpad; k += 16) dst[(size_t)co * a.Kpad + k] = 0.f;
+  }
+}
+
 // dw[i] += part[0][i] + part[1][i] + ... (16-byte units).  Workgroup = 8 units x 32 partial groups: thread (unit, group) adds
 // partials group, group + 32, ... in order, the 32 group sums are combined in group order through LDS (fixed association:
 // bit-reproducible); hundreds of partial tiles of only 10 KB each, so the parallelism has to come from the partial index
@@ -224,6 +379,16 @@ hipError_t launch_wgrad_c16(const WgradArgs& a0, hipStream_t st) {
   if (!a.part || a.part_floats < need) { a.part = wgrad_op_scratch(); a.part_floats = wgrad_wino_scratch_floats(); }     // single-operator entry points
   if (!a.part || a.part_floats < need) return hipErrorOutOfMemory;
   const bool head = a.Cout == 4;
+  if (!head && a.prec == 2 && a.xmax) {                     // fp16x3 precision modes: two workgroups per CU (75.5 KB of LDS each)
+    int nwg2 = device_cu_count() * 2; if (nwg2 > g.ntiles) nwg2 = g.ntiles;
+    const size_t lds16 = (size_t)2 * kFBuf;
+    static DevOnce lds_attr16;
+    { hipError_t e = lds_attr16.set_max_lds((const void*)wgrad_c16_f16_kernel, lds16); if (e != hipSuccess) return e; }
+    UWM_LAUNCH(32, a.flops, a.bytes, wgrad_c16_f16_kernel, dim3((unsigned)nwg2), dim3(256), lds16, st, a, g);
+    const int n4h = a.wrows * a.Kpad / 4;
+    hipLaunchKernelGGL(wgrad_c16_reduce_kernel, dim3((unsigned)((n4h + 7) / 8)), dim3(256), 0, st, (const float*)a.part, nwg2, n4h, a.dw);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)(kTileF + kPatchF) * sizeof(float);      // (the head's dY planes and the final [4][9][256] sums fit inside)
   if (!head) {
     UWM_LAUNCH(32, a.flops, a.bytes, wgrad_c16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, g);

@@ -224,10 +224,13 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
             (int)wgrad_patch_applicable(a0), a0.flops * 1e-9);
   // force_igemm: 0 auto (Winograd-domain -> patch -> flattened), 1 flattened implicit GEMM only, 2 no Winograd, 4 = wgrad_gemm.hip wherever applicable
   if ((a0.force_igemm & 0xff) == 4) return launch_wgrad_gemm(a0, st);
+  static const bool no_up2 = dbg_flag("UWM_NO_UP2") || dbg_flag("UWM_NO_UP2_WGRAD");
+  if (((a0.force_igemm & 0xff) == 0 || (a0.force_igemm & 0xff) == 6) && a0.prec == 2 && a0.xmax && !no_up2 && wgrad_up2_applicable(a0) && wgrad_up2_f16_shape(a0))
+    return launch_wgrad_up2(a0, st);      // sub-pixel form of conv-after-upsample on its fp16x3 kernel (2.25x fewer products than the direct form below)
   if (((a0.force_igemm & 0xff) == 0 || (a0.force_igemm & 0xff) == 6) && a0.prec == 2 && wgrad_f16x3_applicable(a0)) return launch_wgrad_f16x3(a0, st);      // fp16x3 direct form
   if ((a0.force_igemm & 0xff) == 6 && a0.prec == 2 && wgrad_stem_applicable(a0)) return launch_wgrad_stem(a0, st);      // (its fp16x3 kernel)
+  if ((a0.force_igemm & 0xff) == 6 && a0.prec == 2 && a0.Cout == 16 && wgrad_c16_applicable(a0)) return launch_wgrad_c16(a0, st);      // (likewise)
   if ((a0.force_igemm & 0xff) == 6) return hipErrorInvalidValue;
-  static const bool no_up2 = dbg_flag("UWM_NO_UP2") || dbg_flag("UWM_NO_UP2_WGRAD");
   if ((a0.force_igemm & 0xff) == 0 && !no_up2 && wgrad_up2_applicable(a0)) return launch_wgrad_up2(a0, st);      // sub-pixel form of conv-after-upsample
   if ((a0.force_igemm & 0xff) == 0 && wgrad_stem_applicable(a0)) return launch_wgrad_stem(a0, st);         // the ResNet stem: compact K = 147
   if ((a0.force_igemm & 0xff) == 0 && wgrad_gemm_preferred(a0)) return launch_wgrad_gemm(a0, st);        // 1x1 / stride 1: persistent LDS-DMA GEMM, deterministic
