@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 R=/root/repo; cd $R
-timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "up2 or c16 or stem" 2>&1 | tail -5
+timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "c16" 2>&1 | tail -8
 cd /tmp
-UWM_SIDE_STREAM=0 timeout -k 10 200 rocprofv3 --kernel-trace -d $R/gpurun_out/tl4 -o x -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --alt-steps 0 --serial-steps 0 --prof-steps 0 > /dev/null 2>&1 || exit 1
-python $R/scripts/kstat.py $R/gpurun_out/tl4 c16 stem up2 head
+UWM_SIDE_STREAM=0 timeout -k 10 200 rocprofv3 --kernel-trace -d $R/gpurun_out/tl7 -o x -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --alt-steps 0 --serial-steps 0 --prof-steps 0 > /dev/null 2>&1 || exit 1
+python $R/scripts/kstat.py $R/gpurun_out/tl7 c16 "f16x3_kernelILi1"
 cd $R && bash scripts/_ab.sh

@@ -18,7 +18,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _PKG_DIR = Path(__file__).resolve().parent
 _CSRC = _PKG_DIR / "csrc"
 LIB_PATH = _PKG_DIR / "libuwm.so"
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "conv_wino_x3.hip", "conv_f16x3.hip", "conv_f16x3v2.hip", "conv_stem_f16x3.hip", "conv_up2.hip", "conv_up2_f16.hip", "conv_gemm.hip", "conv_head.hip", "mbconv.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "wgrad_f16x3.hip", "wgrad_c16.hip", "wgrad_gemm.hip", "wgrad_stem.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_patch16.hip", "conv_wino.hip", "conv_wino8.hip", "conv_wino_x3.hip", "conv_f16x3.hip", "conv_f16x3v2.hip", "conv_stem_f16x3.hip", "conv_up2.hip", "conv_up2_f16.hip", "conv_c16_f16.hip", "conv_gemm.hip", "conv_head.hip", "mbconv.hip", "wgrad_igemm.hip", "wgrad_patch.hip", "wgrad_wino.hip", "wgrad_f16x3.hip", "wgrad_c16.hip", "wgrad_gemm.hip", "wgrad_stem.hip", "elementwise.hip", "loss.hip", "uwm_model.hip"]
 HIP_ARCH = "gfx950"
 # per-file compiler flags.  The fp16x3 kernels interleave their staging VALU work with MFMAs; hipcc turns the f4 arithmetic of that
 # work into packed v_pk_{fma,mul,add}_f32, which cost more than two plain VALU instructions beside MFMAs (MI355X_MICROARCH.md,
