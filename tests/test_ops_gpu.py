@@ -1103,6 +1103,67 @@ def test_conv_c16_f16x3_forward_and_dgrad(cuda, n, h, w):
     assert derr["f16x3"] != derr["f32"]
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,cfg", [(2, 64, 256, 32, 48, 864), (1, 256, 64, 64, 64, 864), (1, 512, 128, 32, 32, 928), (4, 256, 64, 128, 128, -1)])
+def test_conv_gemm_f16x3_1x1(cuda, n, cin, cout, h, w, cfg):
+    """conv_gemm.hip's F16 form (ConvArgs::ig16; the Bottleneck 1x1 / stride-1 layers in the fp16x3 precision modes): raw fp32 chunks by
+    LDS-DMA, operands split into fp16 hi / lo halves after ds_read, one v_mfma_f32_16x16x32_f16 k-step per 32-channel chunk.  Forward
+    with a lazy BatchNorm + ReLU source (negative scales) and statistics (cfg 864 / 928 = the 64- / 128-channel tiles forced, -1 = auto
+    on a launch big enough for the persistent GEMM); dgrad (auto route) with dY ~ 1e-6, addend and ReLU mask.  Against fp64 within 4x
+    the exact-fp32 kernel's own error."""
+    L = lib()
+    g = torch.Generator().manual_seed(91 + cin)
+    x = torch.randn(n, cin, h, w, generator=g) * 2.0
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    sc = torch.rand(cin, generator=g) + 0.5; sc[::5] *= -1
+    sh = torch.randn(cin, generator=g) * 0.2
+    act = torch.relu(x * sc[:, None, None] + sh[:, None, None])
+    ref = F.conv2d(act.double(), wt.double())
+    xd = nhwc(x).to(cuda); scd, shd = sc.to(cuda), sh.to(cuda)
+    wp, kpad = pack_w(wt)
+    wp = wp.to(cuda)
+    errs = {}
+    for name, on in (("f32", 0), ("f16x3", 1)):
+        L.lib().uwm_op_set_igemm_f16x3(on)
+        try:
+            y = torch.full((n, h, w, cout), float("nan"), device=cuda)
+            stats = torch.zeros(2 * cout, dtype=torch.float64, device=cuda)
+            s0 = src(xd, scd, shd, relu=1)
+            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), cout, kpad, 1, 1, 1, 0, n, cout, None, P(y), P(stats), cfg, stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib().uwm_op_set_igemm_f16x3(0)
+        d = (nchw(y.cpu()).double() - ref).abs()
+        errs[name] = float((d / ref.abs().amax((0, 2, 3), keepdim=True)).max())
+        assert torch.allclose(stats[:cout].cpu(), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+    assert errs["f16x3"] < 4 * errs["f32"] + 1e-7 and errs["f16x3"] < 2e-5, errs
+    assert errs["f16x3"] != errs["f32"]
+    # ---- dgrad: K = the layer's OUTPUT channels
+    xg = torch.randn(n, cin, h, w, generator=g).double().requires_grad_()
+    yg = F.conv2d(xg, wt.double())
+    dy = torch.randn(yg.shape, generator=g) * 1e-6
+    yg.backward(dy.double())
+    kpadd = rup(cout, 32)
+    wd = torch.empty(cin, kpadd, device=cuda)
+    L.check(L.lib().uwm_op_pack_dgrad(P(wp), cout, kpad, 1, cin, P(wd), kpadd, cout, stream()))
+    dyd = nhwc(dy).to(cuda)
+    addend = torch.randn(n, h, w, cin, generator=g) * 1e-6
+    maskt = torch.randn(n, h, w, cin, generator=g)
+    add_d, mask_d = addend.to(cuda), maskt.to(cuda)
+    ref_dx = (xg.grad.permute(0, 2, 3, 1) + addend.double()) * (maskt > 0)
+    derr = {}
+    for name, on in (("f32", 0), ("f16x3", 1)):
+        L.lib().uwm_op_set_igemm_f16x3(on)
+        try:
+            dx = torch.full((n, h, w, cin), float("nan"), device=cuda)
+            L.check(L.lib().uwm_op_dgrad(P(dyd), n, h, w, cout, P(wd), cin, kpadd, 1, 1, 1, 0, h, w, P(add_d), P(mask_d), None, None, P(dx), stream()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib().uwm_op_set_igemm_f16x3(0)
+        derr[name] = float((dx.cpu().double() - ref_dx).abs().max() / ref_dx.abs().max())
+    assert derr["f16x3"] < 4 * derr["f32"] + 1e-7 and derr["f16x3"] < 2e-5, derr
+    assert derr["f16x3"] != derr["f32"]
+
+
 def test_conv_f16x3_upsample_concat(cuda):
     """decoder conv1 on the fp16x3 kernel: cat(nearest_x2(d), skip), both sources lazy, concat boundary on a 16-channel chunk."""
     L = lib()

@@ -15,6 +15,12 @@
 // statistics or fused BatchNorm-backward sums with bnb_y); statistics are accumulated across the tiles of one channel tile and
 // leave as one set of atomics per (workgroup, channel tile).
 //
+// F16 = true (ConvArgs::ig16: the fp16x3 precision modes, layers whose channel counts are multiples of 32): the SAME pipeline and LDS
+// image — raw fp32 chunks by LDS-DMA — and the operands are split into fp16 hi / lo halves in registers after ds_read (the place the
+// lazy BatchNorm + ReLU already sits): a 32-channel chunk is ONE k-step of v_mfma_f32_16x16x32_f16, three products per tile (24 MFMAs
+// of 16 cycles per wave and chunk where the fp32 form issues 64 of 32 cycles); weights times 2^12, a dgrad's dY by the power of two
+// its maximum calls for (ConvArgs::xmax), both leave in the epilogue.
+//
 // Reference semantics replaced: the 1x1 nn.Conv2d layers of torchvision's Bottleneck / efficientnet_pytorch's MBConvBlock as smp
 // wraps them (/root/reference/src/models/unet_model.py:64-71 -> smp encoders).
 #include "uwm_kernels.h"
@@ -30,8 +36,21 @@ __device__ __forceinline__ void gemm_glds16(const float* g, float* l) {      // 
 }
 
 constexpr int kGM = 128;                         // pixels per tile
+constexpr float kGWScale = 4096.f;
+typedef _Float16 g_h8 __attribute__((ext_vector_type(8)));
+typedef unsigned g_u4 __attribute__((ext_vector_type(4)));
+// 8 consecutive channels (two f4) -> the hi and lo fp16 fragments of one v_mfma_f32_16x16x32_f16 operand lane
+__device__ __forceinline__ void gemm_split8(f4 a0, f4 a1, g_h8& hi, g_h8& lo) {
+  uwm_u2 h0, l0, h1, l1;
+  uwm_split4(__builtin_amdgcn_fmed3f(a0.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(a0.y, -65504.f, 65504.f),
+             __builtin_amdgcn_fmed3f(a0.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(a0.w, -65504.f, 65504.f), h0, l0);
+  uwm_split4(__builtin_amdgcn_fmed3f(a1.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(a1.y, -65504.f, 65504.f),
+             __builtin_amdgcn_fmed3f(a1.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(a1.w, -65504.f, 65504.f), h1, l1);
+  hi = __builtin_bit_cast(g_h8, (g_u4){h0.x, h0.y, h1.x, h1.y});
+  lo = __builtin_bit_cast(g_h8, (g_u4){l0.x, l0.y, l1.x, l1.y});
+}
 
-template <int BN>
+template <int BN, bool F16 = false>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(const ConvArgs a, int tilesM, int ntiles) {
   constexpr int NI = BN / 32;                    // 16-channel MFMA tiles per wave (2 x 2 waves)
   constexpr int MI = 4;
@@ -82,10 +101,19 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
   auto lazy_load = [&](int kc, int par) {
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
-      const int k = min(kc * 32 + (k16 * 4 + lq) * 4, a.Ctot - 4);
+      // fp32 form: this lane's k of MFMA k16 = channels (k16*4 + lq)*4 ..; F16: the lane's 8 channels lq*8 .. as two quads
+      const int k = min(kc * 32 + (F16 ? (lq * 2 + k16) : (k16 * 4 + lq)) * 4, a.Ctot - 4);
       lsc[par][k16] = *(const f4*)(a.s0.scale + k); lsh[par][k16] = *(const f4*)(a.s0.shift + k);
     }
   };
+  float dys = 1.f;                                // F16: power-of-two scale of a dgrad's dY
+  if (F16 && a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); dys = ldexpf(1.f, 14 - e); }
+  }
+  const float unscale = F16 ? 1.f / (kGWScale * dys) : 1.f;
 
   f4 acc[MI][NI];
 #pragma unroll
@@ -154,6 +182,42 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
     }
     const float* const xs = smem + cur * kStage;
     const float* const ws = xs + kGM * 32;
+    if (F16) {
+      g_h8 xh[MI], xl[MI], wh[NI], wl[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = (wm * MI + i) * 16 + lrow;
+        const int sw = (row >> 1) & 7;
+        f4 a0 = *(const f4*)(xs + row * 32 + (((2 * lq) ^ sw) << 2)), a1 = *(const f4*)(xs + row * 32 + (((2 * lq + 1) ^ sw) << 2));
+        if (lazy) {
+          a0 = a0 * lsc[cur][0] + lsh[cur][0]; a1 = a1 * lsc[cur][1] + lsh[cur][1];
+          if (relu) {
+            a0.x = fmaxf(a0.x, 0.f); a0.y = fmaxf(a0.y, 0.f); a0.z = fmaxf(a0.z, 0.f); a0.w = fmaxf(a0.w, 0.f);
+            a1.x = fmaxf(a1.x, 0.f); a1.y = fmaxf(a1.y, 0.f); a1.z = fmaxf(a1.z, 0.f); a1.w = fmaxf(a1.w, 0.f);
+          }
+        } else { a0 = a0 * dys; a1 = a1 * dys; }
+        gemm_split8(a0, a1, xh[i], xl[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = (wn * NI + j) * 16 + lrow;
+        const int sw = (row >> 1) & 7;
+        const f4 a0 = *(const f4*)(ws + row * 32 + (((2 * lq) ^ sw) << 2)) * kGWScale, a1 = *(const f4*)(ws + row * 32 + (((2 * lq + 1) ^ sw) << 2)) * kGWScale;
+        gemm_split8(a0, a1, wh[j], wl[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+    } else
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
       f4 xf[MI], wf[NI];
@@ -204,7 +268,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_gemm_kernel(cons
         for (int j = 0; j < NI; ++j) {
           const int co = n0 + (wn * NI + j) * 16 + lq * 4;
           if (mv && co < a.Cout) {
-            f4 v = acc[i][j];
+            f4 v = acc[i][j] * unscale;
             if (co + 3 >= a.wrows) {                               // padded output channels: rows past wrows were duplicates
               if (co + 0 >= a.wrows) v.x = 0.f;
               if (co + 1 >= a.wrows) v.y = 0.f;
@@ -253,17 +317,22 @@ bool conv_gemm_applicable(const ConvArgs& a) {
          a.M >= kGM && a.Cout >= 32 && (a.Cout & 3) == 0 && a.wrows >= 1 && a.prec == 0;
 }
 
-template <int BN>
-static hipError_t launch_gemm(const ConvArgs& a, hipStream_t st, int cls) {
+template <int BN, bool F16>
+static hipError_t launch_gemm_(const ConvArgs& a, hipStream_t st, int cls) {
   const int tilesM = (a.M + kGM - 1) / kGM, tilesN = (a.Cout + BN - 1) / BN;
   const int ntiles = tilesM * tilesN;
   const size_t lds = (size_t)(2 * (kGM + BN) * 32 + 2 * BN * 2) * sizeof(float);
   const int slots = (BN == 64 ? 3 : 2) * device_cu_count();      // resident workgroups: 148 VGPRs / 48 KB LDS at BN = 64, 215 / 64 KB at 128
   const int nwg = ntiles < slots ? ntiles : slots;
   static DevOnce lds_attr;
-  { hipError_t e = lds_attr.set_max_lds((const void*)conv_gemm_kernel<BN>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_gemm_kernel<BN>), dim3((unsigned)nwg), dim3(256), lds, st, a, tilesM, ntiles);
+  { hipError_t e = lds_attr.set_max_lds((const void*)conv_gemm_kernel<BN, F16>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_gemm_kernel<BN, F16>), dim3((unsigned)nwg), dim3(256), lds, st, a, tilesM, ntiles);
   return hipGetLastError();
+}
+template <int BN>
+static hipError_t launch_gemm(const ConvArgs& a, hipStream_t st, int cls) {
+  // fp16x3 form: whole 32-channel chunks (a partial last chunk reads duplicate units against zero weight columns in the fp32 form only)
+  return (a.ig16 && (a.Ctot & 31) == 0) ? launch_gemm_<BN, true>(a, st, cls) : launch_gemm_<BN, false>(a, st, cls);
 }
 
 // bn: 0 auto | 128 | 64 output channels per tile
