@@ -37,9 +37,11 @@ if ROOT not in sys.path:
 WINO_RATIO = 2.25            # direct-conv multiplies per Winograd F(2x2,3x3) multiply (36 / 16)
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak (= fp32 vector peak)
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (v_mfma_f32_16x16x32_{f16,bf16})
-F16X3_DTYPE = ("f32 storage and accumulation; the 3x3 stride-1 convolution products (forward, data and weight gradients) as fp16x3 "
+F16X3_DTYPE = ("f32 storage and accumulation; the convolution products of the encoder and decoder layers (3x3, 7x7 stem, stride-2 and 1x1 "
+               "layers: forward, data gradients, and the weight gradients of the stride-1 3x3 layers and the stem) as fp16x3 "
                "splits - every fp32 operand = two fp16 halves (22 mantissa bits), a*b = ah*bh + ah*bl + al*bh on "
-               "v_mfma_f32_16x16x32_f16, exact power-of-two range scaling; every other kernel exact fp32")
+               "v_mfma_f32_16x16x32_f16, exact power-of-two range scaling; the segmentation head, the stride-2 / 1x1 weight gradients "
+               "and every other kernel exact fp32")
 
 
 def cpu_baseline(encoder: str, hw: int, budget_s: float = 25.0, arch: str = "Unet", batch: int = 16, decoder_channels=None,
