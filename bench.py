@@ -183,7 +183,7 @@ def collect_prof(L, steps):
             name = L.lib().uwm_prof_class_name(c).decode()
             wino = "wino" in name or "up2" in name       # Winograd F(2x2,3x3) and the sub-pixel form of conv-after-upsample: the MFMA pipe executes 16 multiplies per 36 direct ones
             f16 = "f16x3" in name                        # direct form, three half-precision MFMAs per product block: 3x the direct FLOPs on the f16 pipe
-            factor = 3.0 if f16 else (1.0 / WINO_RATIO if wino else 1.0)
+            factor = (3.0 if f16 else 1.0) * (1.0 / WINO_RATIO if wino else 1.0)      # (the sub-pixel fp16x3 kernels: both)
             ents[name] = {"kernel": name, "launches_per_step": cnt / max(1, steps), "avg_us": round(1e3 * ms / cnt, 2),
                           "ms_per_step": round(ms / max(1, steps), 3),
                           "mfma_tflops": round(fl * factor / ms / 1e9, 2),

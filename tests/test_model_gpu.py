@@ -599,6 +599,12 @@ def _expect_f16x3_headline_routing(routing):
         assert any("wgrad_f16x3" in k for k in by[("wgrad", layer)]), (layer, by[("wgrad", layer)])
     assert any("conv_f16x3" in k for k in by[("dgrad", "encoder.layer1.0.conv2")])
     assert any("conv_stem_f16x3" in k for k in by[("fwd", "encoder.conv1")])
+    # round 4, second half: decoder block 4 and the stem's weight gradient on their own fp16x3 kernels
+    for key, kern in ((("fwd", "decoder.blocks.4.conv1.0"), "conv_up2_f16_kernel"), (("dgrad", "decoder.blocks.4.conv1.0"), "conv_up2_dgrad_f16_kernel"),
+                      (("wgrad", "decoder.blocks.4.conv1.0"), "wgrad_up2_f16_kernel"), (("fwd", "decoder.blocks.4.conv2.0"), "conv_c16_f16_kernel"),
+                      (("dgrad", "decoder.blocks.4.conv2.0"), "conv_c16_f16_kernel"), (("wgrad", "decoder.blocks.4.conv2.0"), "wgrad_c16_f16_kernel"),
+                      (("wgrad", "encoder.conv1"), "wgrad_stem_f16_kernel")):
+        assert any(kern in k for k in by[key]), (key, by[key])
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16x3_all"])

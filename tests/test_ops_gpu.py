@@ -645,6 +645,47 @@ def test_wgrad_up2_f16x3(cuda, n, hs, ws):
     assert err["f16x3"] < 4 * err["f32"] + 1e-7 and err["f16x3"] < 1e-5, err
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 64, 128, 32, 32, 3, 2, 1),    # layer2.0.conv1: 3x3 stride 2 (128 x 128 tiles)
+    (2, 64, 128, 32, 32, 1, 2, 0),    # downsample 1x1 stride 2 (Kpad 64: the 128 x 64 tile)
+    (1, 128, 256, 16, 24, 3, 2, 1),   # layer3.0.conv1, a ragged last pixel step
+    (3, 32, 64, 16, 16, 3, 2, 1),     # 64 output rows: the 64 x 128 tile
+])
+def test_wgrad_igemm_f16x3_stride2_layers(cuda, shape):
+    """wgrad_igemm.hip's fp16x3 form (force 7: WgradArgs::prec == 2 on the flattened implicit GEMM — the stride-2 layers' weight
+    gradients in the f16x3_all modes): a 32-pixel step = one v_mfma_f32_16x16x32_f16 k-step, operands split while staged, transposing
+    LDS reads.  Lazy BatchNorm + ReLU input with negative scales, dY ~ 1e-6 (scaled through max|dY|); against fp64 autograd within 4x
+    the exact-fp32 kernel's own error; bit-identical between two launches."""
+    L = lib()
+    n, cin, cout, h, w, k, st, p = shape
+    g = torch.Generator().manual_seed(17 + cin)
+    xr = torch.randn(n, cin, h, w, generator=g) * 2.0
+    sc = torch.rand(cin, generator=g) + 0.5; sc[::5] *= -1
+    sh = torch.randn(cin, generator=g) * 0.2
+    x = torch.relu(xr * sc[:, None, None] + sh[:, None, None]).double()
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).double().requires_grad_()
+    y = F.conv2d(x, wt, None, st, p)
+    ho, wo = y.shape[-2:]
+    dy = torch.randn(y.shape, generator=g) * 1e-6
+    y.backward(dy.double())
+    kpad = rup(k * k * cin, 32)
+    xd, dyd = nhwc(xr).to(cuda), nhwc(dy).to(cuda)
+    scd, shd = sc.to(cuda), sh.to(cuda)
+    s0 = src(xd, scd, shd, relu=1)
+    outs = {}
+    for name, force in (("f32", 1), ("f16x3", 7), ("again", 7)):
+        dw = torch.zeros(cout, kpad, device=cuda)
+        L.check(L.lib().uwm_op_wgrad(C.byref(s0), None, P(dyd), n, ho, wo, cout, cout, kpad, k, k, st, p, P(dw), force, stream()))
+        torch.cuda.synchronize()
+        outs[name] = dw.cpu()
+    assert torch.equal(outs["f16x3"], outs["again"])
+    assert not torch.equal(outs["f16x3"], outs["f32"])          # (the fp16x3 kernel did run)
+    ref = wt.grad
+    err = {kk: float((unpack_w(outs[kk], cout, cin, k, k).double() - ref).abs().max() / ref.abs().max()) for kk in ("f32", "f16x3")}
+    assert err["f16x3"] < 4 * err["f32"] + 1e-7 and err["f16x3"] < 1e-5, err
+    assert (outs["f16x3"][:, k * k * cin:] == 0).all()
+
+
 def test_maxpool_ties_and_lazy_input(cuda):
     """3x3 s2 p1 max-pool over relu(bn(y)): post-ReLU zeros tie; the FIRST max in scan order wins,
     as torch's CPU kernel does, so the argmax (and with it the backward) matches."""

@@ -231,7 +231,7 @@ hipError_t launch_conv_c16_f16(const ConvArgs& a, hipStream_t st) {
   const int nwg = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_c16_f16_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(31, a.flops, a.bytes, conv_c16_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+  UWM_LAUNCH(48, a.flops, a.bytes, conv_c16_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
   return hipGetLastError();
 }
 

@@ -326,7 +326,7 @@ static hipError_t launch_gemm_(const ConvArgs& a, hipStream_t st, int cls) {
   const int nwg = ntiles < slots ? ntiles : slots;
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_gemm_kernel<BN, F16>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_gemm_kernel<BN, F16>), dim3((unsigned)nwg), dim3(256), lds, st, a, tilesM, ntiles);
+  UWM_LAUNCH(F16 ? (BN == 128 ? 51 : 52) : cls, a.flops, a.bytes, (conv_gemm_kernel<BN, F16>), dim3((unsigned)nwg), dim3(256), lds, st, a, tilesM, ntiles);
   return hipGetLastError();
 }
 template <int BN>

@@ -346,7 +346,7 @@ static hipError_t launch_cfg_(const ConvArgs& a, hipStream_t st, int cls) {
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
   static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_igemm_kernel<BM, BN, WM, WN, false, F16>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, false, F16>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
+  UWM_LAUNCH(F16 ? 53 + cls : cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, false, F16>), dim3((unsigned)(tilesM * tilesN)), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 template <int BM, int BN, int WM, int WN>
@@ -379,7 +379,7 @@ static hipError_t launch_s2_dgrad_(const ConvArgs& a0, hipStream_t st, int cls) 
       for (int s = 0; s < a.kw; ++s)         // tap (r, s) reaches an input pixel iff (ho - r + off) and (wo - s + off) are even
         if (((((pc >> 1) - r + a.off) | ((pc & 1) - s + a.off)) & 1) == 0) { a.pc_taps[pc] |= (unsigned)(r * a.kw + s) << (4 * a.pc_ntaps[pc]); ++a.pc_ntaps[pc]; }
   }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, true, F16>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
+  UWM_LAUNCH(F16 ? 53 + cls : cls, a.flops, a.bytes, (conv_igemm_kernel<BM, BN, WM, WN, true, F16>), dim3((unsigned)(tilesM * tilesN), 4), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -223,7 +223,7 @@ hipError_t launch_conv_up2_f16(const ConvArgs& a, hipStream_t st) {
   const int nwg = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_up2_f16_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(34, a.flops, a.bytes, conv_up2_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+  UWM_LAUNCH(45, a.flops, a.bytes, conv_up2_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
   return hipGetLastError();
 }
 
@@ -403,7 +403,7 @@ hipError_t launch_conv_up2_dgrad_f16(const ConvArgs& a, hipStream_t st) {
   const int nwg = ntiles < 2 * device_cu_count() ? ntiles : 2 * device_cu_count();
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)conv_up2_dgrad_f16_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(35, a.flops, a.bytes, conv_up2_dgrad_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+  UWM_LAUNCH(46, a.flops, a.bytes, conv_up2_dgrad_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
   return hipGetLastError();
 }
 
@@ -583,7 +583,7 @@ hipError_t launch_wgrad_up2_f16(const WgradArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * kWBuf;
   static DevOnce lds_attr;
   { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_up2_f16_kernel, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(36, a.flops, a.bytes, wgrad_up2_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
+  UWM_LAUNCH(47, a.flops, a.bytes, wgrad_up2_f16_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, ntiles);
   return hipGetLastError();
 }
 

@@ -839,7 +839,13 @@ const char* prof_class_name(int cls) {
       "wgrad_head_kernel",              "conv_up2_kernel",                "conv_up2_dgrad_kernel",
       "wgrad_up2_kernel",               "conv_gemm_kernel<128>",          "conv_gemm_kernel<64>",
       "wgrad_gemm_kernel<128>",         "wgrad_gemm_kernel<64>",          "wgrad_stem_kernel",
-      "conv_f16x3_kernel",              "wgrad_f16x3_kernel",             "conv_stem_f16x3_kernel"};
+      "conv_f16x3_kernel",              "wgrad_f16x3_kernel",             "conv_stem_f16x3_kernel",
+      "conv_up2_f16x3_kernel",          "conv_up2_dgrad_f16x3_kernel",    "wgrad_up2_f16x3_kernel",
+      "conv_c16_f16x3_kernel",          "wgrad_c16_f16x3_kernel",         "wgrad_stem_f16x3_kernel",
+      "conv_gemm_f16x3_kernel<128>",    "conv_gemm_f16x3_kernel<64>",
+      "conv_igemm_f16x3_kernel<128,128,2,2>", "conv_igemm_f16x3_kernel<128,64,2,2>", "conv_igemm_f16x3_kernel<128,32,4,1>",
+      "conv_igemm_f16x3_kernel<128,16,4,1>",  "conv_igemm_f16x3_kernel<64,64,2,2>",  "conv_igemm_f16x3_kernel<64,128,1,4>",
+      "?", "wgrad_igemm_f16x3_kernel<128,128,2,2>", "wgrad_igemm_f16x3_kernel<128,64,2,2>", "wgrad_igemm_f16x3_kernel<64,128,2,2>", "?"};
   return (cls >= 0 && cls < kProfClasses) ? names[cls] : "?";
 }
 

@@ -160,7 +160,7 @@ struct WgradArgs {           // dW[co][k] += sum_m dY[m][co] * X[m][k]   (k = ta
 // ---- optional HIP-event profiler: one (start, stop) event pair per conv / wgrad launch, recorded on
 // the launch stream; classes 0..5 = conv_igemm tile configs, 6..9 = wgrad tiles 64x128, 128x128, 16x256, 32x256,
 // 10..13 = conv_patch BN 128, 64, 32, 16 ; 14..16 = wgrad_patch TA 16, 32, 64 ; 17..18 = conv_patch16 BN 16, 32
-enum { kProfClasses = 45 };   // 44 = conv_stem_f16x3 ; 43 = wgrad_f16x3 ; 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
+enum { kProfClasses = 64 };   // 60..62 = wgrad_igemm_f16x3 tiles 128x128, 128x64, 64x128 ; 45 = conv_up2_f16x3 ; 46 = conv_up2_dgrad_f16x3 ; 47 = wgrad_up2_f16x3 ; 48 = conv_c16_f16x3 ; 49 = wgrad_c16_f16x3 ; 50 = wgrad_stem_f16x3 ; 51..52 = conv_gemm_f16x3 BN 128, 64 ; 53..58 = conv_igemm_f16x3 tile configurations 0..5 ; 44 = conv_stem_f16x3 ; 43 = wgrad_f16x3 ; 42 = conv_f16x3 ; 41 = wgrad_stem ; 39..40 = wgrad_gemm TA 128, 64 ; 37..38 = conv_gemm BN 128, 64 ; 34 = conv_up2 ; 35 = conv_up2_dgrad ; 36 = wgrad_up2 ; 31 = conv_wino_x3 (bf16x3) ; 32 = wgrad_c16 ; 33 = wgrad_head ; 19..21 = conv_wino BN 64, 32, 16 ; 22..24 = wgrad_wino TA 64, 32, 16 ; 25 = conv_wino8 ; 26..29 = wgrad tiles 128x32, 128x64, 32x64, 32x128 ; 30 = conv_head
 void prof_enable(bool on);
 bool prof_on();
 void prof_pair(int cls, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);

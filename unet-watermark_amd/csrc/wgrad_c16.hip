@@ -384,7 +384,7 @@ hipError_t launch_wgrad_c16(const WgradArgs& a0, hipStream_t st) {
     const size_t lds16 = (size_t)2 * kFBuf;
     static DevOnce lds_attr16;
     { hipError_t e = lds_attr16.set_max_lds((const void*)wgrad_c16_f16_kernel, lds16); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(32, a.flops, a.bytes, wgrad_c16_f16_kernel, dim3((unsigned)nwg2), dim3(256), lds16, st, a, g);
+    UWM_LAUNCH(49, a.flops, a.bytes, wgrad_c16_f16_kernel, dim3((unsigned)nwg2), dim3(256), lds16, st, a, g);
     const int n4h = a.wrows * a.Kpad / 4;
     hipLaunchKernelGGL(wgrad_c16_reduce_kernel, dim3((unsigned)((n4h + 7) / 8)), dim3(256), 0, st, (const float*)a.part, nwg2, n4h, a.dw);
     return hipGetLastError();

@@ -12,6 +12,12 @@
 // images in a fixed order — no float atomics: the gradient is bit-reproducible (round 3; the atomics also
 // cost 1.76x the algorithmic HBM traffic).  nsplit == 1 adds straight into the pre-zeroed dW.
 //
+// F16 = true (round 4; WgradArgs::prec == 2 with xmax: the stride-2 layers in the f16x3_all modes): the same walk on
+// v_mfma_f32_16x16x32_f16 — a 32-pixel step is ONE k-step, three split products per tile (48 MFMAs of 16 cycles per wave and step at
+// 128 x 128 where the fp32 form issues 128 of 32 cycles).  Both operands are split into fp16 hi / lo planes while they are staged
+// ([32 px][columns] rows of halfs, 32 bytes of padding per row) and read with the transposing load ds_read_b64_tr_b16; dY is scaled
+// by the power of two its maximum calls for (WgradArgs::xmax), which leaves with the partial image.
+//
 // Replaces the weight-gradient half of autograd's conv2d backward.
 #include "uwm_kernels.h"
 #include <cstdio>
@@ -25,9 +31,23 @@ __device__ __forceinline__ unsigned fdivw(unsigned n, FastDiv f) {
   return f.d <= 1 ? n : __umulhi(n, f.mg);
 }
 
-template <int TA, int TB, int WA, int WB>
+typedef _Float16 wi_h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 wi_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) wi_fp16x4 wi_lds_fp16x4;
+__device__ __forceinline__ wi_h8 wi_tr_pair(const char* base, int o0, int o1) {      // two transposed reads -> one 8-half operand fragment
+  const wi_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((wi_lds_fp16x4*)(uintptr_t)(base + o0));
+  const wi_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((wi_lds_fp16x4*)(uintptr_t)(base + o1));
+  typedef __fp16 fp16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+  const fp16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(wi_h8, v);
+}
+
+template <int TA, int TB, int WA, int WB, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) {
   constexpr int LA = TA + 16, LB = TB + 16;          // LDS row strides (== 16 mod 32)
+  constexpr int RSA = TA * 2 + 32, RSB = TB * 2 + 32;      // F16: bytes per pixel row of a half-plane
+  constexpr int PLA = 32 * RSA, PLB = 32 * RSB;            // F16: bytes per plane; a stage buffer = [A hi | A lo | B hi | B lo]
+  constexpr int STG = 2 * PLA + 2 * PLB;
   constexpr int UA = TA / 4, RA = (256 / UA) > 32 ? 32 : (256 / UA), PA = 32 / RA;
   constexpr int UB = TB / 4, RB = (256 / UB) > 32 ? 32 : (256 / UB), PB = 32 / RB;
   constexpr int MI = TA / WA / 16, NI = TB / WB / 16;
@@ -35,7 +55,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const As = smem;                  // [2][32][LA]
   float* const Bs = smem + 2 * 32 * LA;    // [2][32][LB]
-  int* const Rw = (int*)(Bs + 2 * 32 * LB);   // [2][32][4]: per pixel row {n, ho*stride-pad, wo*stride-pad, valid}
+  int* const Rw = F16 ? (int*)((char*)smem + 2 * STG) : (int*)(Bs + 2 * 32 * LB);   // [2][32][4]: per pixel row {n, ho*stride-pad, wo*stride-pad, valid}
+  char* const Hs = (char*)smem;            // F16: [2 stages][STG bytes]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave / WB, wb = wave % WB;
@@ -86,6 +107,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
 
   f4 ar[PA], br[PB];
   unsigned bvalid = 0;
+  float xs = 1.f;                                    // F16: power-of-two scale of dY
+  if (F16 && a.xmax) {
+    float mx = a.xmax[lane & 31];
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    if (mx > 0.f && mx < 3.0e38f) { int e; (void)frexpf(mx, &e); xs = ldexpf(1.f, 14 - e); }
+  }
 
   // one thread per pixel row decomposes m -> (n, ho, wo) for a whole step; everyone else reads LDS
   auto row_info = [&](int st) {
@@ -122,6 +150,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
     }
   };
   auto store_step = [&](int buf) {
+    if (F16) {
+      char* const hb = Hs + buf * STG;
+      if (a_act) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const f4 v = ar[i] * xs;                     // (below 2^14 by construction: no clamp)
+          uwm_u2 hi, lo;
+          uwm_split4(v.x, v.y, v.z, v.w, hi, lo);
+          char* const p_ = hb + (ra + RA * i) * RSA + ua * 8;
+          *(uwm_u2*)p_ = hi; *(uwm_u2*)(p_ + PLA) = lo;
+        }
+      }
+      if (b_act) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+          f4 v = br[i];
+          if (thas) {
+            v = v * tsc + tsh;
+            if (trelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (!((bvalid >> i) & 1u)) v = (f4){0.f, 0.f, 0.f, 0.f};
+          }
+          uwm_u2 hi, lo;
+          uwm_split4(__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f),
+                     __builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f), hi, lo);
+          char* const p_ = hb + 2 * PLA + (rb + RB * i) * RSB + ub * 8;
+          *(uwm_u2*)p_ = hi; *(uwm_u2*)(p_ + PLB) = lo;
+        }
+      }
+      return;
+    }
     float* as = As + buf * 32 * LA;
     float* bs = Bs + buf * 32 * LB;
     if (a_act) {
@@ -155,6 +213,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
     const int cur = st & 1;
     load_step(st + 1);                               // reads row table slot (st+1)&1 (rows past mend are masked)
     row_info(st + 2);                                // writes slot st&1 (last read while loading step st)
+    if (F16) {
+      // lane = (k-group kg, row-in-group q, column quad p): pixel rows 8 kg + q (+4), 8 bytes = 4 consecutive columns
+      const int kg = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+      const char* const hb = Hs + cur * STG;
+      const char* const pa = hb + (8 * kg + q) * RSA + (wa * (TA / WA)) * 2 + p * 8;
+      const char* const pb = hb + 2 * PLA + (8 * kg + q) * RSB + (wb * (TB / WB)) * 2 + p * 8;
+      wi_h8 ah[MI], al[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { ah[i] = wi_tr_pair(pa + i * 32, 0, 4 * RSA); al[i] = wi_tr_pair(pa + i * 32 + PLA, 0, 4 * RSA); }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const wi_h8 bh = wi_tr_pair(pb + j * 32, 0, 4 * RSB), bl = wi_tr_pair(pb + j * 32 + PLB, 0, 4 * RSB);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      store_step(cur ^ 1);
+      __syncthreads();
+      continue;
+    }
     const float* as = As + cur * 32 * LA + wa * (TA / WA) + li;
     const float* bs = Bs + cur * 32 * LB + wb * (TB / WB) + li;
     // fragments are read one k4-step ahead of the MFMAs that use them (register double buffer)
@@ -184,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
   }
 
   // D[i = co][j = kcol]: lane reg e -> co = lq*4 + e, kcol = li
+  const float ixs = 1.f / xs;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -193,20 +276,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const WgradArgs a) 
       for (int e = 0; e < 4; ++e) {
         const int row = a0 + wa * (TA / WA) + i * 16 + lq * 4 + e;
         if (row < a.wrows && kc < a.Kpad) {
-          if (a.nsplit > 1) a.part[((size_t)split * a.wrows + row) * a.Kpad + kc] = acc[i][j][e];      // this split's partial image
-          else a.dw[(size_t)row * a.Kpad + kc] += acc[i][j][e];                                       // the only writer of this element
+          if (a.nsplit > 1) a.part[((size_t)split * a.wrows + row) * a.Kpad + kc] = acc[i][j][e] * ixs;      // this split's partial image
+          else a.dw[(size_t)row * a.Kpad + kc] += acc[i][j][e] * ixs;                                       // the only writer of this element
         }
       }
     }
 }
 
-template <int TA, int TB, int WA, int WB>
+template <int TA, int TB, int WA, int WB, bool F16 = false>
 static hipError_t launch_w(const WgradArgs& a, hipStream_t st, int cls) {
   const int tilesA = (a.wrows + TA - 1) / TA, tilesB = (a.Kpad + TB - 1) / TB;
-  const size_t lds = (size_t)2 * 32 * (TA + 16 + TB + 16) * sizeof(float) + 2 * 32 * 4 * sizeof(int);
+  const size_t lds = (F16 ? (size_t)2 * (2 * 32 * (TA * 2 + 32) + 2 * 32 * (TB * 2 + 32)) : (size_t)2 * 32 * (TA + 16 + TB + 16) * sizeof(float)) + 2 * 32 * 4 * sizeof(int);
   static DevOnce lds_attr;                  // hipFuncSetAttribute is per device
-  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_igemm_kernel<TA, TB, WA, WB>, lds); if (e != hipSuccess) return e; }
-  UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_igemm_kernel<TA, TB, WA, WB>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
+  { hipError_t e = lds_attr.set_max_lds((const void*)wgrad_igemm_kernel<TA, TB, WA, WB, F16>, lds); if (e != hipSuccess) return e; }
+  UWM_LAUNCH(cls, a.flops, a.bytes, (wgrad_igemm_kernel<TA, TB, WA, WB, F16>), dim3((unsigned)(tilesA * tilesB * a.nsplit)), dim3(256), lds, st, a);
   if (a.nsplit > 1) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -236,7 +319,7 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   if ((a0.force_igemm & 0xff) == 0 && wgrad_gemm_preferred(a0)) return launch_wgrad_gemm(a0, st);        // 1x1 / stride 1: persistent LDS-DMA GEMM, deterministic
   if ((a0.force_igemm & 0xff) == 0 && wgrad_c16_applicable(a0)) return launch_wgrad_c16(a0, st);      // 16-channel full-resolution layers, head
   if ((a0.force_igemm & 0xff) == 0 && wino_mode_of(a0.wino) != 0 && wgrad_wino_applicable(a0)) return launch_wgrad_wino(a0, st);
-  if ((a0.force_igemm & 0xff) != 1 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);
+  if ((a0.force_igemm & 0xff) != 1 && (a0.force_igemm & 0xff) != 7 && wgrad_patch_applicable(a0)) return launch_wgrad_patch(a0, st);      // (7 = tests: the flattened implicit GEMM in its fp16x3 form)
   WgradArgs a = a0;
   if (a.M <= 0 || (a.Cout & 3) || (a.Kpad & 31) || (a.Ctot & 3) || (a.C0 & 3)) return hipErrorInvalidValue;
   int TA, TB;
@@ -274,6 +357,12 @@ hipError_t launch_wgrad(const WgradArgs& a0, hipStream_t st) {
   msplit = (msplit + 31) & ~31;
   nsplit = (a.M + msplit - 1) / msplit;
   a.nsplit = nsplit; a.msplit = msplit;
+  // fp16x3 form (the stride-2 layers in the f16x3_all modes; channel counts in whole 32s): 128- and 64-row tiles
+  static const bool no_f16 = dbg_flag("UWM_NO_WGRAD_IG16");
+  const bool f16 = !no_f16 && a.prec == 2 && a.xmax && ((a.force_igemm & 0xff) == 0 || (a.force_igemm & 0xff) == 7) && (a.Ctot & 31) == 0 && (a.Cout & 31) == 0;
+  if (f16 && TA == 128 && TB == 128) return launch_w<128, 128, 2, 2, true>(a, st, 60);
+  if (f16 && TA == 128 && TB == 64) return launch_w<128, 64, 2, 2, true>(a, st, 61);
+  if (f16 && TA == 64 && TB == 128) return launch_w<64, 128, 2, 2, true>(a, st, 62);
   switch (TA) {
     case 16: return launch_w<16, 256, 1, 4>(a, st, 8);
     case 32:

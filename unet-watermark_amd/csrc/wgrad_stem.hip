@@ -390,7 +390,7 @@ hipError_t launch_wgrad_stem(const WgradArgs& a0, hipStream_t st) {
     const size_t lds16 = (size_t)2 * kHBuf;
     static DevOnce lds_attr16;
     { hipError_t e = lds_attr16.set_max_lds((const void*)wgrad_stem_f16_kernel, lds16); if (e != hipSuccess) return e; }
-    UWM_LAUNCH(41, a.flops, a.bytes, wgrad_stem_f16_kernel, dim3((unsigned)nwg), dim3(256), lds16, st, a, ntiles);
+    UWM_LAUNCH(50, a.flops, a.bytes, wgrad_stem_f16_kernel, dim3((unsigned)nwg), dim3(256), lds16, st, a, ntiles);
     hipLaunchKernelGGL(wgrad_stem_f16_reduce_kernel, dim3((64 * 196 + 7) / 8), dim3(256), 0, st, (const float*)a.part, nwg, a.dw, a.wrows, a.Kpad);
     return hipGetLastError();
   }
