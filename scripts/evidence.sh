@@ -5,7 +5,7 @@
 #   <tag>_pmc_summary.json, pmc_traffic.json   FETCH_SIZE / WRITE_SIZE / MFMA-busy passes digested by scripts/pmc_summary.py
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-T=${1:-r04_y}
+T=${1:-r04_z}
 export GIT_SHA=${GIT_SHA:-unknown}      # the GPU box has no .git: pass the commit in (GIT_SHA=$(git rev-parse --short HEAD) gpurun ...)
 if [ "$2" = "tests" ]; then
   timeout -k 10 1100 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_gpu_tests.log; tail -3 gpurun_out/${T}_gpu_tests.log
