@@ -1081,52 +1081,52 @@ def test_conv_up2_f16x3_forward_and_dgrad(cuda, n, hs, ws, lazy):
     assert derr["f16x3"] < 4 * derr["f32"] + 1e-7 and derr["f16x3"] < 1e-5, derr
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 16, 64), (1, 8, 32), (3, 40, 96)])
-def test_conv_c16_f16x3_forward_and_dgrad(cuda, n, h, w):
-    """decoder block 4 conv2 (3x3, 16 -> 16 at full resolution) on conv_c16_f16.hip (ConvArgs::ig16; cfg 710 forced, -1 auto): tap
+@pytest.mark.parametrize("n,h,w,ch", [(2, 16, 64, 16), (1, 8, 32, 16), (3, 40, 96, 16), (2, 16, 64, 32), (1, 8, 32, 32), (3, 24, 96, 32), (12, 64, 256, 32), (10, 64, 256, 16)])      # (the last two: several tiles per persistent workgroup)
+def test_conv_c16_f16x3_forward_and_dgrad(cuda, n, h, w, ch):
+    """decoder block 4 conv2 (3x3, 16 -> 16 at full resolution) on conv_c16_f16.hip (ConvArgs::ig16; cfg 710 forced, -1 auto) and block 3 conv2 (32 -> 32, conv_c32_f16_kernel: cfg 711): tap
     pairs as MFMA k-steps, persistent double-buffered patch.  Forward: lazy BatchNorm + ReLU source (negative scales), output and
     BatchNorm statistics; dgrad: dY ~ 1e-6 (scaled through max|dY|), addend + ReLU mask with lazy mask scale / shift.  Against fp64
     within 4x the exact-fp32 routes' own error."""
     L = lib()
     g = torch.Generator().manual_seed(81 + h)
-    x = torch.randn(n, 16, h, w, generator=g) * 2.0
-    sc = torch.rand(16, generator=g) + 0.5; sc[::5] *= -1
-    sh = torch.randn(16, generator=g) * 0.3
-    wt = torch.randn(16, 16, 3, 3, generator=g) * 0.1
+    x = torch.randn(n, ch, h, w, generator=g) * 2.0
+    sc = torch.rand(ch, generator=g) + 0.5; sc[::5] *= -1
+    sh = torch.randn(ch, generator=g) * 0.3
+    wt = torch.randn(ch, ch, 3, 3, generator=g) * 0.1
     act = torch.relu(x * sc[:, None, None] + sh[:, None, None])
     ref = F.conv2d(act.double(), wt.double(), None, 1, 1)
     xd = nhwc(x).to(cuda); scd, shd = sc.to(cuda), sh.to(cuda)
     wp, kpad = pack_w(wt)
     wp = wp.to(cuda)
     errs = {}
-    for name, on, cfg in (("f32", 0, -1), ("f16x3", 1, -1), ("forced", 1, 710)):
+    for name, on, cfg in (("f32", 0, -1), ("f16x3", 1, -1), ("forced", 1, 710 if ch == 16 else 711)):
         L.lib().uwm_op_set_igemm_f16x3(on)
         try:
-            y = torch.full((n, h, w, 16), float("nan"), device=cuda)
-            stats = torch.zeros(32, dtype=torch.float64, device=cuda)
+            y = torch.full((n, h, w, ch), float("nan"), device=cuda)
+            stats = torch.zeros(2 * ch, dtype=torch.float64, device=cuda)
             s0 = src(xd, scd, shd, relu=1)
-            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), 16, kpad, 3, 3, 1, 1, n, 16, None, P(y), P(stats), cfg, stream()))
+            L.check(L.lib().uwm_op_conv(C.byref(s0), None, P(wp), ch, kpad, 3, 3, 1, 1, n, ch, None, P(y), P(stats), cfg, stream()))
             torch.cuda.synchronize()
         finally:
             L.lib().uwm_op_set_igemm_f16x3(0)
         errs[name] = float((nchw(y.cpu()).double() - ref).abs().max() / ref.abs().max())
-        assert torch.allclose(stats[:16].cpu(), ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * float(ref.abs().max()))
-        assert torch.allclose(stats[16:].cpu(), (ref * ref).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(stats[:ch].cpu(), ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * float(ref.abs().max()))
+        assert torch.allclose(stats[ch:].cpu(), (ref * ref).sum((0, 2, 3)), rtol=1e-5, atol=1e-3 * float((ref * ref).sum((0, 2, 3)).max()))
         if name == "f16x3": y16 = y.clone()
         if name == "forced": assert torch.equal(y, y16)                     # (the auto route under ig16 IS this kernel)
     assert errs["f16x3"] < 4 * errs["f32"] + 1e-7 and errs["f16x3"] < 1e-5, errs
     assert errs["f16x3"] != errs["f32"]
     # ---- dgrad with addend + lazily activated ReLU mask
-    xg = torch.randn(n, 16, h, w, generator=g).double().requires_grad_()
+    xg = torch.randn(n, ch, h, w, generator=g).double().requires_grad_()
     yg = F.conv2d(xg, wt.double(), None, 1, 1)
     dy = torch.randn(yg.shape, generator=g) * 1e-6
     yg.backward(dy.double())
-    kpadd = rup(9 * 16, 32)
-    wd = torch.empty(16, kpadd, device=cuda)
-    L.check(L.lib().uwm_op_pack_dgrad(P(wp), 16, kpad, 9, 16, P(wd), kpadd, 16, stream()))
+    kpadd = rup(9 * ch, 32)
+    wd = torch.empty(ch, kpadd, device=cuda)
+    L.check(L.lib().uwm_op_pack_dgrad(P(wp), ch, kpad, 9, ch, P(wd), kpadd, ch, stream()))
     dyd = nhwc(dy).to(cuda)
-    addend = torch.randn(n, h, w, 16, generator=g) * 1e-6
-    maskt = torch.randn(n, h, w, 16, generator=g)
+    addend = torch.randn(n, h, w, ch, generator=g) * 1e-6
+    maskt = torch.randn(n, h, w, ch, generator=g)
     add_d, mask_d = addend.to(cuda), maskt.to(cuda)
     live = (maskt * sc + sh) > 0
     ref_dx = (xg.grad.permute(0, 2, 3, 1) + addend.double()) * live
@@ -1134,8 +1134,8 @@ def test_conv_c16_f16x3_forward_and_dgrad(cuda, n, h, w):
     for name, on in (("f32", 0), ("f16x3", 1)):
         L.lib().uwm_op_set_igemm_f16x3(on)
         try:
-            dx = torch.full((n, h, w, 16), float("nan"), device=cuda)
-            L.check(L.lib().uwm_op_dgrad(P(dyd), n, h, w, 16, P(wd), 16, kpadd, 3, 3, 1, 1, h, w, P(add_d), P(mask_d), P(scd), P(shd), P(dx), stream()))
+            dx = torch.full((n, h, w, ch), float("nan"), device=cuda)
+            L.check(L.lib().uwm_op_dgrad(P(dyd), n, h, w, ch, P(wd), ch, kpadd, 3, 3, 1, 1, h, w, P(add_d), P(mask_d), P(scd), P(shd), P(dx), stream()))
             torch.cuda.synchronize()
         finally:
             L.lib().uwm_op_set_igemm_f16x3(0)

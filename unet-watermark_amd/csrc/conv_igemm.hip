@@ -403,7 +403,7 @@ int device_cu_count() {
 // conv_up2_dgrad_kernel, conv_igemm_kernel, conv_c16_f16_kernel
 // (with a.bnb_y set: only the epilogues that read yhat from a separate tensor count — conv_wino_kernel<NI> and conv_igemm_kernel)
 bool conv_epilogue_carries_bnb(const ConvArgs& a) {
-  if (a.ig16 && a.prec != 2 && conv_c16_f16_applicable(a)) return true;      // conv_c16_f16_kernel (dgrad epilogue)
+  if (a.ig16 && a.prec != 2 && (conv_c16_f16_applicable(a) || conv_c32_f16_applicable(a))) return true;      // conv_c16_f16_kernel / conv_c32_f16_kernel (dgrad epilogue)
   if (a.prec == 2) return !a.out_up && (a.wu_layout == 1 ? conv_f16x3v2_applicable(a) : conv_f16x3_applicable(a));
   if (a.bnb_y) {
     if (a.out_up || a.prec == 1) return false;
@@ -436,7 +436,8 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t st, int force_cfg) {
             a.rmul < 0 ? "dgrad" : "fwd", a.N, a.Ctot, a.C0, a.s0.up, a.Cout, a.Ho, a.Wo, a.Hl, a.Wl, a.ntaps, a.smul, a.sdiv,
             (int)(cfg < 0 && wino_mode_of(a.wino) != 0 && conv_wino_applicable(a)), a.flops * 1e-9);
   if (cfg == 700) return launch_conv_up2(a, st);
-  if (cfg == 710 || (cfg < 0 && a.ig16 && a.prec != 2 && conv_c16_f16_applicable(a))) return launch_conv_c16_f16(a, st);      // 16 -> 16 at full resolution, fp16x3
+  if (cfg == 710 || (cfg < 0 && a.ig16 && a.prec != 2 && conv_c16_f16_applicable(a))) return launch_conv_c16_f16(a, st);
+  if (cfg == 711 || (cfg < 0 && a.ig16 && a.prec != 2 && conv_c32_f16_applicable(a))) return launch_conv_c32_f16(a, st);      // 32 -> 32, fp16x3      // 16 -> 16 at full resolution, fp16x3
   if (cfg >= 800 && cfg < 1000) return launch_conv_gemm(a, st, cfg - 800);
   if (cfg == 500) return launch_conv_head(a, st);
   if ((cfg >= 600 && cfg <= 607) || (cfg < 0 && a.prec == 2)) return launch_conv_f16x3(a, st, cfg >= 600 ? cfg - 600 : 0);      // fp16x3 direct form: the bank behind a.wu is a conv_f16x3.hip one

@@ -222,6 +222,8 @@ hipError_t launch_conv_up2_dgrad_f16(const ConvArgs& a, hipStream_t st);
 // conv_c16_f16.hip: 3x3 from 16 to 16 channels at full resolution (decoder block 4 conv2), forward and dgrad, fp16x3 (taken when ConvArgs::ig16 is set); force_cfg 710
 bool conv_c16_f16_applicable(const ConvArgs& a);
 hipError_t launch_conv_c16_f16(const ConvArgs& a, hipStream_t st);
+bool conv_c32_f16_applicable(const ConvArgs& a);          // the same for 32 -> 32 channels (decoder block 3 conv2); force_cfg 711
+hipError_t launch_conv_c32_f16(const ConvArgs& a, hipStream_t st);
 bool wgrad_up2_f16_shape(const WgradArgs& a);             // its weight gradient: 2 x 32 low-resolution tiles
 int wgrad_up2_f16_parts(const WgradArgs& a);              // workgroup partials of that launch (wgrad_up2_kernel's layout)
 hipError_t launch_wgrad_up2_f16(const WgradArgs& a, hipStream_t st);
