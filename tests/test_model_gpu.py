@@ -1239,7 +1239,10 @@ def test_trainer_hipgraph_step_matches_eager(cuda):
         x, t = O.synthetic_batch(*shape, seed=40 + k)
         la = ta.step(x.to(cuda), t.to(cuda)).clone()
         lb = tb.step(x.to(cuda), t.to(cuda)).clone()
-        assert torch.allclose(la, lb, rtol=0, atol=5e-4), (k, la, lb)
+        # (two EAGER trainers drift apart at the same rate over these 8 steps — fp64-atomic BatchNorm sums land in a different order,
+        # lr 1e-3 amplifies it: measured 1e-5 / 1e-4 / 3e-4 at k = 4 / 6 / 7 with both pairings, 6e-4 once; a disturbed buffer would
+        # show as O(0.1))
+        assert torch.allclose(la, lb, rtol=0, atol=5e-4 if k < 6 else 2e-3), (k, la, lb)
         if k in (3, 4):                                    # a bigger eval forward re-plans (and re-allocates) the model's workspace
             for mdl in (a, b):
                 mdl.eval()
