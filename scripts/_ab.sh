@@ -1,3 +1,4 @@
+# (baseline library: scripts/build_baseline_lib.sh <rev>)
 # same-box A/B: the committed build (abl/libuwm_base.so) against the working tree, alternating runs
 export TMPDIR=/tmp
 B="--steps 60 --warmup 15 --no-cpu-baseline --alt-steps 0 --serial-steps 0 --prof-steps 0 ${AB_ARGS}"
