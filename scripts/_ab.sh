@@ -1,7 +1,7 @@
 # (baseline library: scripts/build_baseline_lib.sh <rev>)
 # same-box A/B: the committed build (abl/libuwm_base.so) against the working tree, alternating runs
 export TMPDIR=/tmp
-B="--steps 60 --warmup 15 --no-cpu-baseline --alt-steps 0 --serial-steps 0 --prof-steps 0 ${AB_ARGS}"
+B="--steps ${AB_STEPS:-60} --warmup ${AB_WARM:-15} --no-cpu-baseline --alt-steps 0 --serial-steps 0 --prof-steps 0 ${AB_ARGS}"
 for i in 1 2 3; do
   for v in new base; do
     if [ $v = base ]; then export UWM_LIB=$PWD/unet-watermark_amd/abl/libuwm_base.so; else unset UWM_LIB; fi
